@@ -1,0 +1,162 @@
+/*
+ * nbpp.h - C ABI of the MI355X (gfx950) particle-particle gravity library.
+ *
+ * One shared library, libnbpp.so, replaces the body of the reference's
+ *     void ParticleSystem::compute_pp_forces(const Config&)
+ * (reference src/particles.h:62, src/particles.cpp:133-367): direct-summation
+ * PP forces and the P3M short-range tapered force, fp64, periodic minimum-image
+ * wrap, Plummer softening, "acc += sum" semantics.  All entry points are plain C:
+ * pointers, sizes and PODs only.  Every function returns NBPP_OK (0) or a negative
+ * nbpp_status; nothing throws; nbpp_last_error() returns the message of the last
+ * failure on the calling thread.
+ *
+ * There is no CPU fallback: every compute entry point fails with NBPP_ERR_HIP when
+ * no gfx950 device can be opened.
+ */
+#ifndef NBPP_H
+#define NBPP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum nbpp_status {
+    NBPP_OK = 0,
+    NBPP_ERR_ARG = -1,     /* null pointer, negative size, inconsistent parameters */
+    NBPP_ERR_HIP = -2,     /* a HIP runtime call failed (message has the HIP error) */
+    NBPP_ERR_NOINIT = -3,  /* nbpp_init() has not been called (or failed)          */
+    NBPP_ERR_RANGE = -4,   /* a size exceeds what the entry point supports         */
+    NBPP_ERR_NOMEM = -5    /* device or host allocation failed                     */
+} nbpp_status;
+
+/*
+ * The scalars the reference hoists out of Config at the top of compute_pp_forces
+ * (src/particles.cpp:134-152), one field per hoisted value, plus the two Config
+ * fields its cell search uses (MESH_SIZE, CELL_SIZE).
+ *
+ *   use_pm == 0 : direct summation.  Every ordered pair (i, j != i) contributes once,
+ *                 with the minimum-image displacement and Plummer softening soft_sq.
+ *                 cutoff_sq, r_switch*, trans_width, pm_soft_sq are ignored
+ *                 (src/particles.cpp:326,331,339 are all guarded by use_pm).
+ *   use_pm != 0 : P3M short range.  Pairs with r^2 > cutoff_sq contribute nothing;
+ *                 r^2 > r_switch_sq is tapered by S = 2x^3 - 3x^2 + 1,
+ *                 x = (r - r_switch)/trans_width; the mesh-softened force
+ *                 G m d / (r^2 + pm_soft_sq)^(3/2) is subtracted.
+ *
+ * mesh_size / cell_size are only used to size the library's own search grid; the
+ * library never reads the reference's host linked list.
+ */
+typedef struct nbpp_params {
+    double domain_size;  /* Config::DOMAIN_SIZE              src/particles.cpp:143 */
+    double G;            /* Config::G                        src/particles.cpp:144 */
+    double soft_sq;      /* Config::SOFTENING_SQUARED        src/particles.cpp:145 */
+    double pm_soft_sq;   /* (0.5*CELL_SIZE)^2                src/particles.cpp:146-147 */
+    double r_switch;     /* Config::R_SWITCH_START           src/particles.cpp:148 */
+    double r_switch_sq;  /* Config::R_SWITCH_START_SQ        src/particles.cpp:149 */
+    double cutoff_sq;    /* Config::CUTOFF_RADIUS_SQUARED    src/particles.cpp:150 */
+    double trans_width;  /* Config::CUTOFF_TRANSITION_WIDTH  src/particles.cpp:151 */
+    double cell_size;    /* Config::CELL_SIZE                src/particles.cpp:136,276 */
+    int32_t mesh_size;   /* Config::MESH_SIZE                src/particles.cpp:139 */
+    int32_t use_pm;      /* Config::USE_PM                   src/particles.cpp:152 */
+} nbpp_params;
+
+/* Timing and work counters of the most recent compute call on this thread's device. */
+typedef struct nbpp_stats {
+    double pair_kernel_ms;   /* HIP-event time of the pair kernel(s) alone            */
+    double prepare_ms;       /* sort / binning / packing kernels                      */
+    double total_ms;         /* whole call on the device, first to last kernel        */
+    double h2d_ms, d2h_ms;   /* host-pointer entry points only, else 0                */
+    uint64_t n_sources;      /* j count                                               */
+    uint64_t n_targets;      /* i count                                               */
+    uint64_t pairs_evaluated;/* ordered pairs whose r^2 was formed (i==j excluded)    */
+    uint64_t pairs_accepted; /* P3M: ordered pairs with r^2 <= cutoff_sq (needs
+                                NBPP_OPT_TIMING); direct: equal to pairs_evaluated    */
+    uint64_t pair_launches;  /* pair-kernel launches in the call                      */
+    int32_t  kernel_variant; /* which pair kernel ran (NBPP_KERNEL_*)                 */
+    int32_t  reserved;
+} nbpp_stats;
+
+enum {
+    NBPP_KERNEL_NONE = 0,
+    NBPP_KERNEL_DIRECT = 1,       /* all-pairs, tiles classified for the image shift   */
+    NBPP_KERNEL_DIRECT_WRAP = 2,  /* all-pairs, per-pair minimum image everywhere      */
+    NBPP_KERNEL_P3M_CELLS = 3,    /* counting-sort cell list, cutoff-bounded search    */
+    NBPP_KERNEL_P3M_ALLPAIRS = 4  /* P3M pair function over all pairs (small n, tests) */
+};
+
+/* nbpp_set_option keys */
+enum {
+    NBPP_OPT_FORCE_KERNEL = 1,   /* 0 = automatic, else one of NBPP_KERNEL_*           */
+    NBPP_OPT_TIMING = 2,         /* 1 = record HIP-event timings into nbpp_stats        */
+    NBPP_OPT_TARGETS_PER_LANE = 3, /* all-pairs kernels: 0 = automatic, else 1, 2 or 4  */
+    NBPP_OPT_SOURCE_SPLIT = 4,   /* all-pairs kernels: 0 = automatic, else the number of
+                                    source slices summed separately (blockIdx.y)        */
+    NBPP_OPT_P3M_SEARCH_RADIUS = 5 /* P3M: cells per cutoff radius of the search grid,
+                                    0 = automatic                                        */
+};
+
+/*
+ * Lifecycle.  nbpp_init binds the calling process to HIP device `device` (-1 = current
+ * device), creates the library's stream and events.  Idempotent; nbpp_shutdown frees
+ * every device allocation the library made.
+ * Replaces: the implicit device selection of the reference's `omp target` region
+ * (src/particles.cpp:169).
+ */
+int nbpp_init(int device);
+void nbpp_shutdown(void);
+const char* nbpp_last_error(void);
+int nbpp_set_option(int key, int64_t value);
+int nbpp_get_stats(nbpp_stats* out);
+
+/*
+ * acc_{x,y,z}[i] += sum_{j != i} a_ij for i in [0, n).  HOST pointers, SoA fp64,
+ * blocking, one caller thread.  This is the drop-in for
+ *     ParticleSystem::compute_pp_forces(config)     src/particles.cpp:133
+ * with x,y,z,m = pos_x/pos_y/pos_z/mass and ax,ay,az = acc_x/acc_y/acc_z
+ * (src/particles.h:39-51).  The library owns all device memory.  n == 0 is a no-op.
+ */
+int nbpp_accumulate(const nbpp_params* p, size_t n,
+                    const double* x, const double* y, const double* z, const double* m,
+                    double* ax, double* ay, double* az);
+
+/*
+ * Device-resident form of the same operation (replaces the per-call map(to/tofrom)
+ * re-mapping of src/particles.cpp:169-173).  x,y,z,m are DEVICE pointers to n_src
+ * sources.  Targets are the sub-range [tgt_begin, tgt_begin + n_tgt) of the sources
+ * (the i-partition of a multi-GPU run: each rank passes the all-gathered sources and
+ * its own slice).  ax,ay,az are DEVICE pointers of length n_tgt, indexed by
+ * i - tgt_begin, accumulated into.  Work is enqueued on `stream` (a hipStream_t, or
+ * NULL for the library's own stream); the call returns after enqueueing unless
+ * NBPP_OPT_TIMING is on.
+ */
+int nbpp_accumulate_device(const nbpp_params* p, size_t n_src,
+                           const double* x, const double* y, const double* z,
+                           const double* m, size_t tgt_begin, size_t n_tgt,
+                           double* ax, double* ay, double* az, void* stream);
+
+/*
+ * Device-resident pieces of the caller contract around the hot path.  All pointers are
+ * DEVICE pointers of length n; work is enqueued on `stream`.
+ *
+ * nbpp_kick_device      v += a*(dt/a^3) - v*(2 H dt)          src/integrator.cpp:168-181
+ * nbpp_drift_device     x += v*dt; x -= L*floor(x/L)          src/integrator.cpp:183-198
+ * nbpp_max_accel_sq_device
+ *                       max(1e-9, max_i ax^2+ay^2+az^2) -> *out_host (blocking)
+ *                                                              src/integrator.cpp:200-213
+ */
+int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz,
+                     const double* ax, const double* ay, const double* az,
+                     double dt, double scale_factor, double hubble, void* stream);
+int nbpp_drift_device(size_t n, double* x, double* y, double* z,
+                      const double* vx, const double* vy, const double* vz,
+                      double dt, double domain_size, void* stream);
+int nbpp_max_accel_sq_device(size_t n, const double* ax, const double* ay,
+                             const double* az, double* out_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBPP_H */

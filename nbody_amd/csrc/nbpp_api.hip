@@ -1,0 +1,575 @@
+// nbpp_api.hip - the C ABI of libnbpp (include/nbpp.h): device context, workspace,
+// launch logic.  All device code is in nbpp_kernels.hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/nbpp.h"
+#include "nbpp_kernels.hip.h"
+
+using namespace nbpp;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail(e_ == hipErrorOutOfMemory ? NBPP_ERR_NOMEM : NBPP_ERR_HIP,    \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                    \
+    } while (0)
+
+#define CHK(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != NBPP_OK) return rc_; \
+    } while (0)
+
+// Device buffer that only grows.
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return NBPP_OK;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return NBPP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// One sorted copy of a particle set.
+struct Sorted {
+    Buf cell, rank, order, start, x, y, z, gm, box;
+    int n = 0, npad = 0;
+    void release() {
+        for (Buf* b : {&cell, &rank, &order, &start, &x, &y, &z, &gm, &box}) b->release();
+    }
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    Buf count, blocksum;              // binning scratch (shared by source and target sorts)
+    Sorted src, tgt;
+    Buf part[3];                      // per-slice partial sums
+    Buf host_in[4], host_acc[3];      // staging for the host-pointer entry point
+    Buf canon[3];                     // P3M: positions brought into [0, L)
+    Buf blockmax, counter;
+    int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
+            opt_p3m_radius = 0;
+    nbpp_stats stats{};
+    void release() {
+        for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
+                       &host_in[1], &host_in[2], &host_in[3], &host_acc[0], &host_acc[1],
+                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter})
+            b->release();
+        src.release();
+        tgt.release();
+    }
+};
+
+Ctx g;
+std::mutex g_mu;
+
+inline int cdiv(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
+
+int check_params(const nbpp_params* p) {
+    if (!p) return fail(NBPP_ERR_ARG, "params is NULL");
+    if (!(p->domain_size > 0.0) || !std::isfinite(p->domain_size))
+        return fail(NBPP_ERR_ARG, "domain_size must be positive and finite");
+    if (!(p->soft_sq >= 0.0)) return fail(NBPP_ERR_ARG, "soft_sq must be >= 0");
+    if (!std::isfinite(p->G)) return fail(NBPP_ERR_ARG, "G must be finite");
+    if (p->use_pm) {
+        if (!(p->cutoff_sq > 0.0) || !(p->trans_width > 0.0) || !(p->pm_soft_sq >= 0.0) ||
+            !(p->r_switch >= 0.0))
+            return fail(NBPP_ERR_ARG,
+                        "use_pm needs cutoff_sq > 0, trans_width > 0, pm_soft_sq >= 0, "
+                        "r_switch >= 0");
+    }
+    return NBPP_OK;
+}
+
+PairConsts make_consts(const nbpp_params* p) {
+    PairConsts k;
+    k.L = p->domain_size;
+    k.half_L = 0.5 * p->domain_size;
+    k.eps2 = p->soft_sq;
+    k.eps_pm2 = p->pm_soft_sq;
+    k.r_switch = p->r_switch;
+    k.r_switch_sq = p->r_switch_sq;
+    k.cutoff_sq = p->cutoff_sq;
+    k.inv_width = p->use_pm ? 1.0 / p->trans_width : 0.0;
+    k.qscale = static_cast<double>(1 << QBITS) / p->domain_size;
+    return k;
+}
+
+// Exclusive scan of count[0..n) into start[0..n); n includes the trailing zero entry, so
+// start[n-1] is the grand total.
+int exclusive_scan(int n, const int* count, int* start, hipStream_t s) {
+    const int nblocks = cdiv(n, SCAN_BLOCK);
+    CHK(g.blocksum.ensure(sizeof(int) * (nblocks + 1)));
+    int* bs = g.blocksum.as<int>();
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nblocks), dim3(WG), 0, s, n, count, start, bs);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(WG), 0, s, nblocks, bs, bs + nblocks);
+    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(WG), 0, s, n, start, bs);
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
+// Counting sort of n particles by cell of `grid`; leaves out.order (sorted -> original) and
+// out.start, the cell offsets (ncell + 1 entries).
+int sort_by_cell(int n, const double* x, const double* y, const double* z, const BinGrid& grid,
+                 Sorted& out, hipStream_t s) {
+    const long long ncell = 1LL * grid.nside * grid.nside * grid.nside;
+    if (ncell + 1 > 0x7fffffffLL) return fail(NBPP_ERR_RANGE, "bin grid too large");
+    CHK(g.count.ensure(sizeof(int) * (ncell + 1)));
+    CHK(out.start.ensure(sizeof(int) * (ncell + 1)));
+    CHK(out.cell.ensure(sizeof(int) * n));
+    CHK(out.rank.ensure(sizeof(int) * n));
+    CHK(out.order.ensure(sizeof(int) * n));
+    HIPCHK(hipMemsetAsync(g.count.p, 0, sizeof(int) * (ncell + 1), s));
+    hipLaunchKernelGGL(k_bin_count, dim3(cdiv(n, WG)), dim3(WG), 0, s, n, x, y, z, grid,
+                       out.cell.as<int>(), out.rank.as<int>(), g.count.as<int>());
+    CHK(exclusive_scan(static_cast<int>(ncell + 1), g.count.as<int>(), out.start.as<int>(), s));
+    hipLaunchKernelGGL(k_bin_scatter, dim3(cdiv(n, WG)), dim3(WG), 0, s, n, out.cell.as<int>(),
+                       out.rank.as<int>(), out.start.as<int>(), out.order.as<int>());
+    hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s,
+                       static_cast<int>(ncell), out.start.as<int>(), out.order.as<int>());
+    HIPCHK(hipGetLastError());
+    out.n = n;
+    return NBPP_OK;
+}
+
+// Z-order grid for the direct kernel: power-of-two side, about 8 particles per cell.
+BinGrid direct_grid(int n, double L) {
+    int nside = 1;
+    while (nside < 1024 && 8.0 * (2.0 * nside) * (2.0 * nside) * (2.0 * nside) <= n) nside *= 2;
+    BinGrid gr;
+    gr.nside = nside;
+    gr.scale = nside / L;
+    gr.morton = 1;
+    return gr;
+}
+
+template <int MODE, bool SOFT0>
+int launch_pairs_i(int I, dim3 grid, const PairArgs& a, hipStream_t s) {
+    switch (I) {
+        case 1: hipLaunchKernelGGL((k_pairs<1, MODE, SOFT0>), grid, dim3(WG), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_pairs<2, MODE, SOFT0>), grid, dim3(WG), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_pairs<4, MODE, SOFT0>), grid, dim3(WG), 0, s, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
+int launch_pairs(int mode, bool soft0, int I, dim3 grid, const PairArgs& a, hipStream_t s) {
+    if (mode == 2) return launch_pairs_i<2, true>(I, grid, a, s);
+    if (mode == 1)
+        return soft0 ? launch_pairs_i<1, true>(I, grid, a, s) : launch_pairs_i<1, false>(I, grid, a, s);
+    return soft0 ? launch_pairs_i<0, true>(I, grid, a, s) : launch_pairs_i<0, false>(I, grid, a, s);
+}
+
+// All-pairs path (direct summation, or the P3M pair function over all pairs).
+int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, const double* y,
+                 const double* z, const double* m, int tgt_begin, int n_tgt, double* ax,
+                 double* ay, double* az, hipStream_t s) {
+    const PairConsts k = make_consts(p);
+    const BinGrid grid = direct_grid(n_src, p->domain_size);
+
+    // sources: sort, gather, boxes
+    CHK(sort_by_cell(n_src, x, y, z, grid, g.src, s));
+    const int npad = cdiv(n_src, TJ) * TJ;
+    g.src.npad = npad;
+    for (Buf* b : {&g.src.x, &g.src.y, &g.src.z, &g.src.gm}) CHK(b->ensure(sizeof(double) * npad));
+    CHK(g.src.box.ensure(sizeof(int) * 8 * (npad / SUB)));
+    hipLaunchKernelGGL(k_gather_sources, dim3(npad / WG), dim3(WG), 0, s, n_src, npad,
+                       g.src.order.as<int>(), x, y, z, m, p->G, g.src.x.as<double>(),
+                       g.src.y.as<double>(), g.src.z.as<double>(), g.src.gm.as<double>());
+    hipLaunchKernelGGL(k_source_boxes, dim3(npad / WG), dim3(WG), 0, s, npad,
+                       g.src.x.as<double>(), g.src.y.as<double>(), g.src.z.as<double>(), k.qscale,
+                       g.src.box.as<int>());
+    HIPCHK(hipGetLastError());
+
+    // targets: the sources themselves, or a separately sorted slice
+    const double *tx, *ty, *tz;
+    const int* tperm;
+    if (tgt_begin == 0 && n_tgt == n_src) {
+        tx = g.src.x.as<double>(); ty = g.src.y.as<double>(); tz = g.src.z.as<double>();
+        tperm = g.src.order.as<int>();
+    } else {
+        CHK(sort_by_cell(n_tgt, x + tgt_begin, y + tgt_begin, z + tgt_begin, grid, g.tgt, s));
+        for (Buf* b : {&g.tgt.x, &g.tgt.y, &g.tgt.z}) CHK(b->ensure(sizeof(double) * n_tgt));
+        hipLaunchKernelGGL(k_gather_targets, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, n_tgt, n_tgt,
+                           g.tgt.order.as<int>(), x + tgt_begin, y + tgt_begin, z + tgt_begin,
+                           g.tgt.x.as<double>(), g.tgt.y.as<double>(), g.tgt.z.as<double>());
+        HIPCHK(hipGetLastError());
+        tx = g.tgt.x.as<double>(); ty = g.tgt.y.as<double>(); tz = g.tgt.z.as<double>();
+        tperm = g.tgt.order.as<int>();
+    }
+    if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[1], s));
+
+    // launch shape: I targets per lane, source range split over blockIdx.y when the target
+    // count alone cannot fill 256 CUs
+    int I = n_tgt >= (1 << 19) ? 4 : (n_tgt >= (1 << 17) ? 2 : 1);
+    if (g.opt_force_i == 1 || g.opt_force_i == 2 || g.opt_force_i == 4) I = static_cast<int>(g.opt_force_i);
+    const int blocks_i = cdiv(n_tgt, WG * I);
+    const int n_tiles = npad / TJ;
+    int split = std::min(n_tiles, std::max(1, cdiv(1024, blocks_i)));
+    if (g.opt_force_split > 0) split = std::min<int>(n_tiles, static_cast<int>(g.opt_force_split));
+    const int tiles_per_split = cdiv(n_tiles, split);
+    split = cdiv(n_tiles, tiles_per_split);
+
+    PairArgs a{};
+    a.sx = g.src.x.as<double>(); a.sy = g.src.y.as<double>(); a.sz = g.src.z.as<double>();
+    a.sgm = g.src.gm.as<double>(); a.sbox = g.src.box.as<int>(); a.n_src_pad = npad;
+    a.tx = tx; a.ty = ty; a.tz = tz; a.tperm = tperm; a.n_tgt = n_tgt;
+    a.tiles_per_split = tiles_per_split;
+    a.ax = ax; a.ay = ay; a.az = az;
+    a.n_tgt_pad = cdiv(n_tgt, 64) * 64;
+    a.k = k;
+    if (split > 1) {
+        for (Buf& b : g.part) CHK(b.ensure(sizeof(double) * static_cast<size_t>(split) * a.n_tgt_pad));
+        a.px = g.part[0].as<double>(); a.py = g.part[1].as<double>(); a.pz = g.part[2].as<double>();
+    }
+    const int mode = variant == NBPP_KERNEL_P3M_ALLPAIRS ? 2 : (variant == NBPP_KERNEL_DIRECT_WRAP ? 1 : 0);
+    CHK(launch_pairs(mode, p->soft_sq == 0.0, I, dim3(blocks_i, split), a, s));
+    if (split > 1) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, n_tgt,
+                           a.n_tgt_pad, split, a.px, a.py, a.pz, tperm, ax, ay, az);
+        HIPCHK(hipGetLastError());
+    }
+    g.stats.pairs_evaluated = static_cast<uint64_t>(n_tgt) * static_cast<uint64_t>(n_src - 1);
+    g.stats.pair_launches = 1;
+    return NBPP_OK;
+}
+
+// Search grid of the P3M cell kernel: `radius` cells cover the cutoff radius with a 1e-9
+// relative margin (binning rounds at the 1e-16 level).  Returns false when the box holds
+// fewer than 2*radius + 3 cells per side: then the wrap of a cell index no longer implies
+// the minimum image and the all-pairs kernel is used instead.
+bool p3m_search_grid(const nbpp_params* p, int* radius, int* nside) {
+    const double rc = std::sqrt(p->cutoff_sq) * (1.0 + 1e-9);
+    int R = g.opt_p3m_radius > 0 ? static_cast<int>(g.opt_p3m_radius) : 3;
+    R = std::min(R, 8);
+    const double cells = std::floor(R * p->domain_size / rc);
+    if (!(cells >= 2 * R + 3)) return false;
+    int n = static_cast<int>(std::min(cells, 1290.0));  // 1290^3 < 2^31
+    *radius = R;
+    *nside = n;
+    return true;
+}
+
+int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double* y,
+                  const double* z, const double* m, int tgt_begin, int n_tgt, double* ax,
+                  double* ay, double* az, hipStream_t s) {
+    const PairConsts k = make_consts(p);
+    int R = 0, nside = 0;
+    if (!p3m_search_grid(p, &R, &nside)) return fail(NBPP_ERR_ARG, "box too small for the cell search");
+    BinGrid grid;
+    grid.nside = nside;
+    grid.scale = nside / p->domain_size;
+    grid.morton = 0;
+
+    for (Buf& b : g.canon) CHK(b.ensure(sizeof(double) * n_src));
+    double *cx = g.canon[0].as<double>(), *cy = g.canon[1].as<double>(), *cz = g.canon[2].as<double>();
+    hipLaunchKernelGGL(k_canonical_positions, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z,
+                       p->domain_size, cx, cy, cz);
+    CHK(sort_by_cell(n_src, cx, cy, cz, grid, g.src, s));
+    for (Buf* b : {&g.src.x, &g.src.y, &g.src.z, &g.src.gm}) CHK(b->ensure(sizeof(double) * n_src));
+    hipLaunchKernelGGL(k_gather_sources, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, n_src,
+                       g.src.order.as<int>(), cx, cy, cz, m, p->G, g.src.x.as<double>(),
+                       g.src.y.as<double>(), g.src.z.as<double>(), g.src.gm.as<double>());
+    HIPCHK(hipGetLastError());
+
+    const double *tx, *ty, *tz;
+    const int* tperm;
+    if (tgt_begin == 0 && n_tgt == n_src) {
+        tx = g.src.x.as<double>(); ty = g.src.y.as<double>(); tz = g.src.z.as<double>();
+        tperm = g.src.order.as<int>();
+    } else {
+        CHK(sort_by_cell(n_tgt, cx + tgt_begin, cy + tgt_begin, cz + tgt_begin, grid, g.tgt, s));
+        for (Buf* b : {&g.tgt.x, &g.tgt.y, &g.tgt.z}) CHK(b->ensure(sizeof(double) * n_tgt));
+        hipLaunchKernelGGL(k_gather_targets, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, n_tgt, n_tgt,
+                           g.tgt.order.as<int>(), cx + tgt_begin, cy + tgt_begin, cz + tgt_begin,
+                           g.tgt.x.as<double>(), g.tgt.y.as<double>(), g.tgt.z.as<double>());
+        HIPCHK(hipGetLastError());
+        tx = g.tgt.x.as<double>(); ty = g.tgt.y.as<double>(); tz = g.tgt.z.as<double>();
+        tperm = g.tgt.order.as<int>();
+    }
+    CHK(g.counter.ensure(sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(g.counter.p, 0, sizeof(unsigned long long), s));
+    if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[1], s));
+
+    P3MArgs a{};
+    a.sx = g.src.x.as<double>(); a.sy = g.src.y.as<double>(); a.sz = g.src.z.as<double>();
+    a.sgm = g.src.gm.as<double>(); a.cell_start = g.src.start.as<int>();
+    a.nside = nside; a.R = R; a.cell_scale = grid.scale;
+    a.tx = tx; a.ty = ty; a.tz = tz; a.tperm = tperm; a.n_tgt = n_tgt;
+    a.ax = ax; a.ay = ay; a.az = az;
+    a.accepted = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
+    a.k = k;
+    hipLaunchKernelGGL(k_p3m_cells, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, a);
+    HIPCHK(hipGetLastError());
+    const long long span = 2LL * R + 1;
+    g.stats.pairs_evaluated = 0;  // candidates depend on the data; see pairs_accepted
+    g.stats.pair_launches = 1;
+    (void)span;
+    return NBPP_OK;
+}
+
+int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const double* y,
+                      const double* z, const double* m, size_t tgt_begin, size_t n_tgt,
+                      double* ax, double* ay, double* az, hipStream_t s) {
+    if (n_src > 0x7fffff00ULL) return fail(NBPP_ERR_RANGE, "n_src exceeds 2^31 - 256");
+    g.stats = nbpp_stats{};
+    g.stats.n_sources = n_src;
+    g.stats.n_targets = n_tgt;
+    int variant;
+    if (p->use_pm) {
+        variant = NBPP_KERNEL_P3M_CELLS;
+        int radius, nside;
+        if (g.opt_force_kernel == NBPP_KERNEL_P3M_ALLPAIRS || n_src < 2048 ||
+            !p3m_search_grid(p, &radius, &nside))
+            variant = NBPP_KERNEL_P3M_ALLPAIRS;
+        if (g.opt_force_kernel == NBPP_KERNEL_P3M_CELLS && p3m_search_grid(p, &radius, &nside))
+            variant = NBPP_KERNEL_P3M_CELLS;
+    } else {
+        variant = NBPP_KERNEL_DIRECT;
+        if (g.opt_force_kernel == NBPP_KERNEL_DIRECT_WRAP) variant = NBPP_KERNEL_DIRECT_WRAP;
+    }
+    g.stats.kernel_variant = variant;
+    if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[0], s));
+    if (variant == NBPP_KERNEL_P3M_CELLS) {
+        CHK(run_p3m_cells(p, static_cast<int>(n_src), x, y, z, m, static_cast<int>(tgt_begin),
+                          static_cast<int>(n_tgt), ax, ay, az, s));
+    } else {
+        CHK(run_allpairs(p, variant, static_cast<int>(n_src), x, y, z, m,
+                         static_cast<int>(tgt_begin), static_cast<int>(n_tgt), ax, ay, az, s));
+    }
+    if (g.opt_timing) {
+        HIPCHK(hipEventRecord(g.ev[2], s));
+        HIPCHK(hipEventSynchronize(g.ev[2]));
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, g.ev[0], g.ev[1]));
+        HIPCHK(hipEventElapsedTime(&b, g.ev[1], g.ev[2]));
+        g.stats.prepare_ms = a;
+        g.stats.pair_kernel_ms = b;
+        g.stats.total_ms = a + b;
+        if (variant == NBPP_KERNEL_P3M_CELLS) {
+            unsigned long long hits = 0;
+            HIPCHK(hipMemcpy(&hits, g.counter.p, sizeof(hits), hipMemcpyDeviceToHost));
+            g.stats.pairs_accepted = hits;
+        } else {
+            g.stats.pairs_accepted = g.stats.pairs_evaluated;
+        }
+    }
+    return NBPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nbpp_last_error(void) { return g_err; }
+
+int nbpp_init(int device) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g.ready) return NBPP_OK;
+    int count = 0;
+    HIPCHK(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(NBPP_ERR_HIP, "no HIP device visible");
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    if (device >= count) return fail(NBPP_ERR_ARG, "device %d out of range (%d visible)", device, count);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(NBPP_ERR_HIP, "device %d is %s; libnbpp is built for gfx950 only", device,
+                    prop.gcnArchName);
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    for (auto& e : g.ev) HIPCHK(hipEventCreate(&e));
+    g.device = device;
+    g.ready = true;
+    return NBPP_OK;
+}
+
+void nbpp_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g.ready) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    g.release();
+    for (auto& e : g.ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+    g.ready = false;
+}
+
+int nbpp_set_option(int key, int64_t value) {
+    switch (key) {
+        case NBPP_OPT_FORCE_KERNEL: g.opt_force_kernel = value; return NBPP_OK;
+        case NBPP_OPT_TIMING: g.opt_timing = value; return NBPP_OK;
+        case NBPP_OPT_TARGETS_PER_LANE: g.opt_force_i = value; return NBPP_OK;
+        case NBPP_OPT_SOURCE_SPLIT: g.opt_force_split = value; return NBPP_OK;
+        case NBPP_OPT_P3M_SEARCH_RADIUS: g.opt_p3m_radius = value; return NBPP_OK;
+        default: return fail(NBPP_ERR_ARG, "unknown option key %d", key);
+    }
+}
+
+int nbpp_get_stats(nbpp_stats* out) {
+    if (!out) return fail(NBPP_ERR_ARG, "out is NULL");
+    *out = g.stats;
+    return NBPP_OK;
+}
+
+int nbpp_accumulate_device(const nbpp_params* p, size_t n_src, const double* x, const double* y,
+                           const double* z, const double* m, size_t tgt_begin, size_t n_tgt,
+                           double* ax, double* ay, double* az, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    CHK(check_params(p));
+    if (tgt_begin > n_src || n_tgt > n_src - tgt_begin)
+        return fail(NBPP_ERR_ARG, "target range [%zu, %zu) is outside the %zu sources", tgt_begin,
+                    tgt_begin + n_tgt, n_src);
+    if (n_tgt == 0) return NBPP_OK;
+    if (!x || !y || !z || !m || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    std::lock_guard<std::mutex> lock(g_mu);
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    return compute_on_device(p, n_src, x, y, z, m, tgt_begin, n_tgt, ax, ay, az, s);
+}
+
+int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const double* y,
+                    const double* z, const double* m, double* ax, double* ay, double* az) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    CHK(check_params(p));
+    if (n == 0) return NBPP_OK;
+    if (!x || !y || !z || !m || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    std::lock_guard<std::mutex> lock(g_mu);
+    HIPCHK(hipSetDevice(g.device));
+    const size_t bytes = sizeof(double) * n;
+    const double* hin[4] = {x, y, z, m};
+    hipEvent_t e0 = g.ev[3];
+    for (int c = 0; c < 4; ++c) CHK(g.host_in[c].ensure(bytes));
+    for (int c = 0; c < 3; ++c) CHK(g.host_acc[c].ensure(bytes));
+    auto t0 = std::chrono::steady_clock::now();
+    for (int c = 0; c < 4; ++c)
+        HIPCHK(hipMemcpyAsync(g.host_in[c].p, hin[c], bytes, hipMemcpyHostToDevice, g.stream));
+    // the device sums start from zero; the caller's accumulators are added on the host, which
+    // is the same single rounding as the reference's acc[i] += local (src/particles.cpp:362-364)
+    for (int c = 0; c < 3; ++c) HIPCHK(hipMemsetAsync(g.host_acc[c].p, 0, bytes, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    auto t1 = std::chrono::steady_clock::now();
+    (void)e0;
+    int rc = compute_on_device(p, n, g.host_in[0].as<double>(), g.host_in[1].as<double>(),
+                               g.host_in[2].as<double>(), g.host_in[3].as<double>(), 0, n,
+                               g.host_acc[0].as<double>(), g.host_acc[1].as<double>(),
+                               g.host_acc[2].as<double>(), g.stream);
+    if (rc != NBPP_OK) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    auto t2 = std::chrono::steady_clock::now();
+    std::vector<double> tmp(n);
+    double* hout[3] = {ax, ay, az};
+    for (int c = 0; c < 3; ++c) {
+        HIPCHK(hipMemcpy(tmp.data(), g.host_acc[c].p, bytes, hipMemcpyDeviceToHost));
+        double* o = hout[c];
+        for (size_t i = 0; i < n; ++i) o[i] += tmp[i];
+    }
+    auto t3 = std::chrono::steady_clock::now();
+    g.stats.h2d_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    g.stats.d2h_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    if (!g.opt_timing) g.stats.total_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    return NBPP_OK;
+}
+
+int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz, const double* ax,
+                     const double* ay, const double* az, double dt, double scale_factor,
+                     double hubble, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    if (n == 0) return NBPP_OK;
+    if (!vx || !vy || !vz || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    const double a3 = scale_factor * scale_factor * scale_factor;  // src/integrator.cpp:169
+    const double dt_over_a3 = dt / a3;                             // :170
+    const double dt_2H = dt * 2.0 * hubble;                        // :171
+    const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
+    hipLaunchKernelGGL(k_kick, dim3(blocks), dim3(WG), 0, s, n, vx, vy, vz, ax, ay, az, dt_over_a3,
+                       dt_2H);
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
+int nbpp_drift_device(size_t n, double* x, double* y, double* z, const double* vx,
+                      const double* vy, const double* vz, double dt, double domain_size,
+                      void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    if (n == 0) return NBPP_OK;
+    if (!x || !y || !z || !vx || !vy || !vz) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    if (!(domain_size > 0.0)) return fail(NBPP_ERR_ARG, "domain_size must be positive");
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
+    hipLaunchKernelGGL(k_drift, dim3(blocks), dim3(WG), 0, s, n, x, y, z, vx, vy, vz, dt,
+                       domain_size, 1.0 / domain_size);  // inv_domain: src/integrator.cpp:184
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
+int nbpp_max_accel_sq_device(size_t n, const double* ax, const double* ay, const double* az,
+                             double* out_host, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    if (!out_host) return fail(NBPP_ERR_ARG, "out_host is NULL");
+    *out_host = 1e-9;  // the floor of src/integrator.cpp:201
+    if (n == 0) return NBPP_OK;
+    if (!ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    std::lock_guard<std::mutex> lock(g_mu);
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    const int blocks = std::min(1024, cdiv(static_cast<long long>(n), WG));
+    CHK(g.blockmax.ensure(sizeof(double) * blocks));
+    hipLaunchKernelGGL(k_max_accel_sq, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az,
+                       g.blockmax.as<double>());
+    HIPCHK(hipGetLastError());
+    std::vector<double> h(blocks);
+    HIPCHK(hipMemcpyAsync(h.data(), g.blockmax.p, sizeof(double) * blocks, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double m = 1e-9;
+    for (double v : h) m = (v > m) ? v : m;  // strict '>' as src/integrator.cpp:209
+    *out_host = m;
+    return NBPP_OK;
+}
+
+}  // extern "C"

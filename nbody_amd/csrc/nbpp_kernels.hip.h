@@ -1,0 +1,700 @@
+// nbpp_kernels.hip.h - gfx950 device code of libnbpp: binning, the pair kernels, and the
+// bandwidth-bound caller-contract kernels.  Included once, by nbpp_api.hip.
+//
+// Data layout in HBM: every particle array is SoA fp64 (x[], y[], z[], ...), coalesced
+// by lane.  The pair kernels read a library-owned, spatially sorted copy of the sources
+// (sx, sy, sz, sgm = G*m) and of the targets (tx, ty, tz, tperm).
+//
+// Pair arithmetic follows reference src/particles.cpp:321-359 (identical at :212-254):
+// minimum-image displacement, r^2, optional cutoff / cubic taper / subtractive
+// mesh-softened term, Plummer softening.  Algebraically the reference's
+//     a = G m / q ;  a * d / sqrt(q)         (q = r^2 + eps^2)
+// is evaluated here as d * (G m) * q^(-3/2) with q^(-3/2) from a 24-bit rsqrt seed and
+// one third-order correction (relative error ~3e-16 per pair).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbpp {
+
+constexpr int WG = 256;        // threads per workgroup = 4 wavefronts of 64
+constexpr int TJ = 256;        // sources staged in LDS per tile (8 KiB of 32-B records)
+constexpr int SUB = 64;        // sources per image-classified sub-tile
+constexpr int QBITS = 20;      // bounding boxes are kept in units of L / 2^20
+constexpr int QHALF = 1 << (QBITS - 1);
+
+// ---------------------------------------------------------------------------------
+// Scalars of one call.  Mirrors nbpp_params plus derived reciprocals.
+// ---------------------------------------------------------------------------------
+struct PairConsts {
+    double L, half_L;       // domain size, L/2            (src/math_utils.h:12)
+    double eps2;            // SOFTENING_SQUARED           (src/particles.cpp:145)
+    double eps_pm2;         // (0.5*CELL_SIZE)^2           (src/particles.cpp:146-147)
+    double r_switch;        // R_SWITCH_START              (:148)
+    double r_switch_sq;     // (:149)
+    double cutoff_sq;       // (:150)
+    double inv_width;       // 1 / CUTOFF_TRANSITION_WIDTH (:151, :333)
+    double qscale;          // 2^QBITS / L
+};
+
+// ---------------------------------------------------------------------------------
+// q^(-3/2), q > 0 inside the f32 exponent range.
+// Seed y = rsq_f32(q) (|rel err| < 2^-22), h = 1 - q y^2, then
+//   q^(-3/2) = y^3 (1 - h)^(-3/2) = y^3 (1 + h (3/2 + 15/8 h) + O(h^3)),  |h^3| < 2^-63.
+// y has 24 significant bits, so y*y is exact in fp64.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double inv_cube_root2(double q) {
+    const float yf = __builtin_amdgcn_rsqf(static_cast<float>(q));
+    const double y = static_cast<double>(yf);
+    const double y2 = y * y;
+    const double h = __builtin_fma(-q, y2, 1.0);
+    const double y3 = y * y2;
+    const double c = h * __builtin_fma(1.875, h, 1.5);
+    return __builtin_fma(y3, c, y3);
+}
+
+// Same with the fp64 seed instruction (full exponent range) and a zero guard: used when
+// SOFTENING_SQUARED == 0, where q can be 0 for the self pair or for coincident particles.
+// The reference skips i == j by index (src/particles.cpp:202,302) and produces NaN for
+// two distinct coincident particles with zero softening; this returns 0 for both.
+__device__ __forceinline__ double inv_cube_root2_guarded(double q) {
+    const double y = __builtin_amdgcn_rsq(q);
+    const double y2 = y * y;
+    const double h = __builtin_fma(-q, y2, 1.0);
+    const double y3 = y * y2;
+    const double c = h * __builtin_fma(1.875, h, 1.5);
+    const double r = __builtin_fma(y3, c, y3);
+    return (q > 0.0) ? r : 0.0;
+}
+
+// r = q^(-1/2) to fp64 accuracy from the same seed: y (1 + h (1/2 + 3/8 h)).
+__device__ __forceinline__ double inv_sqrt_refined(double q) {
+    const double y = __builtin_amdgcn_rsq(q);
+    const double h = __builtin_fma(-q * y, y, 1.0);
+    const double c = h * __builtin_fma(0.375, h, 0.5);
+    return __builtin_fma(y, c, y);
+}
+
+// src/math_utils.h:11-16, the same two strict compares.
+__device__ __forceinline__ double min_image(double d, double L, double half_L) {
+    d = (d > half_L) ? d - L : d;
+    d = (d < -half_L) ? d + L : d;
+    return d;
+}
+
+// One source acting on one target, direct summation (use_pm == 0).
+//   (dx,dy,dz) minimum-image displacement, gm = G*m_j.          src/particles.cpp:349-359
+template <bool SOFT0>
+__device__ __forceinline__ void pair_direct(double dx, double dy, double dz, double gm,
+                                            double eps2, double& ax, double& ay, double& az) {
+    const double q = __builtin_fma(dx, dx, __builtin_fma(dy, dy, __builtin_fma(dz, dz, eps2)));
+    double s;
+    if constexpr (SOFT0) {
+        s = gm * inv_cube_root2_guarded(q);
+    } else {
+        // fold gm into the cube: (gm*y)*y^2 keeps the op count of the plain cube
+        const float yf = __builtin_amdgcn_rsqf(static_cast<float>(q));
+        const double y = static_cast<double>(yf);
+        const double y2 = y * y;
+        const double h = __builtin_fma(-q, y2, 1.0);
+        const double y3 = (gm * y) * y2;
+        const double c = h * __builtin_fma(1.875, h, 1.5);
+        s = __builtin_fma(y3, c, y3);
+    }
+    ax = __builtin_fma(s, dx, ax);
+    ay = __builtin_fma(s, dy, ay);
+    az = __builtin_fma(s, dz, az);
+}
+
+// One source acting on one target, P3M short range (use_pm != 0).  src/particles.cpp:324-359
+//   r^2 > cutoff_sq                -> nothing               (:326-328)
+//   r^2 > r_switch_sq              -> S = 2x^3 - 3x^2 + 1   (:330-335)
+//   a += S * (pp - pm_short) * d                            (:339-359)
+__device__ __forceinline__ void pair_p3m(double dx, double dy, double dz, double gm,
+                                         const PairConsts& k, double& ax, double& ay,
+                                         double& az) {
+    const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+    if (r2 > k.cutoff_sq) return;
+    double f = inv_cube_root2_guarded(r2 + k.eps2) - inv_cube_root2_guarded(r2 + k.eps_pm2);
+    if (r2 > k.r_switch_sq) {
+        const double dist = r2 * inv_sqrt_refined(r2);
+        const double t = (dist - k.r_switch) * k.inv_width;
+        const double S = __builtin_fma(t * t, __builtin_fma(2.0, t, -3.0), 1.0);
+        f *= S;
+    }
+    const double s = gm * f;
+    ax = __builtin_fma(s, dx, ax);
+    ay = __builtin_fma(s, dy, ay);
+    az = __builtin_fma(s, dz, az);
+}
+
+// ---------------------------------------------------------------------------------
+// Binning: counting sort of particles by cell.  Replaces the serial head/next linked
+// list of reference src/particles.cpp:50,60-62,81-83,94-96 (src/particles.h:8-24).
+// Final order is (cell, original index): deterministic from run to run.
+// ---------------------------------------------------------------------------------
+struct BinGrid {
+    double scale;   // cells per unit length
+    int nside;      // cells per axis
+    int morton;     // 1: Z-order cell ids (nside must be a power of two <= 1024)
+};
+
+// Cell of a coordinate in [0, L); anything outside (or a product that rounds up to nside)
+// is clamped to the nearest edge cell.
+__device__ __forceinline__ int bin_coord(double x, double scale, int nside) {
+    double c = floor(x * scale);
+    c = fmin(fmax(c, 0.0), static_cast<double>(nside - 1));
+    return static_cast<int>(c);
+}
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__device__ __forceinline__ int cell_id(double x, double y, double z, const BinGrid g) {
+    const int ix = bin_coord(x, g.scale, g.nside);
+    const int iy = bin_coord(y, g.scale, g.nside);
+    const int iz = bin_coord(z, g.scale, g.nside);
+    if (g.morton) return static_cast<int>(spread3(ix) | (spread3(iy) << 1) | (spread3(iz) << 2));
+    return (iz * g.nside + iy) * g.nside + ix;  // x fastest, as src/particles.cpp:94
+}
+
+__global__ void k_bin_count(int n, const double* __restrict__ x, const double* __restrict__ y,
+                            const double* __restrict__ z, BinGrid g, int* __restrict__ cell,
+                            int* __restrict__ rank, int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_id(x[i], y[i], z[i], g);
+    cell[i] = c;
+    rank[i] = atomicAdd(&count[c], 1);
+}
+
+// Exclusive scan in three launches: 2048 entries per block.
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_BLOCK = WG * SCAN_PER_THREAD;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total) {
+    // inclusive scan over 256 threads via wave shuffles + 4 wave totals in LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(WG) k_scan_blocks(int n, const int* __restrict__ in,
+                                                    int* __restrict__ out,
+                                                    int* __restrict__ block_sum) {
+    __shared__ int lds[4];
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+    int v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int total;
+    int run = block_exclusive_scan(s, lds, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+
+// One workgroup scans the per-block totals in place (exclusive) and stores the grand total
+// at out_total[0].
+__global__ void __launch_bounds__(WG) k_scan_totals(int nblocks, int* __restrict__ block_sum,
+                                                    int* __restrict__ out_total) {
+    __shared__ int lds[4];
+    int carry = 0;
+    for (int start = 0; start < nblocks; start += WG) {
+        const int i = start + threadIdx.x;
+        const int v = (i < nblocks) ? block_sum[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, lds, total);
+        if (i < nblocks) block_sum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) out_total[0] = carry;
+}
+
+__global__ void __launch_bounds__(WG) k_scan_add(int n, int* __restrict__ out,
+                                                 const int* __restrict__ block_sum) {
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+    const int add = block_sum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k)
+        if (base + k < n) out[base + k] += add;
+}
+
+__global__ void k_bin_scatter(int n, const int* __restrict__ cell, const int* __restrict__ rank,
+                              const int* __restrict__ start, int* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    order[start[cell[i]] + rank[i]] = i;
+}
+
+// The atomic ranks above depend on arrival order; putting each cell's members in
+// ascending original index makes the sorted order a pure function of the input.
+__global__ void k_cell_canon(int ncell, const int* __restrict__ start, int* __restrict__ order) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const int b = start[c], e = start[c + 1];
+    for (int p = b + 1; p < e; ++p) {
+        const int v = order[p];
+        int q = p - 1;
+        while (q >= b && order[q] > v) {
+            order[q + 1] = order[q];
+            --q;
+        }
+        order[q + 1] = v;
+    }
+}
+
+// Gather the sorted copy.  Entries [n, npad) replicate the last particle with zero mass,
+// so a padded tile never widens a bounding box and never contributes.
+__global__ void k_gather_sources(int n, int npad, const int* __restrict__ order,
+                                 const double* __restrict__ x, const double* __restrict__ y,
+                                 const double* __restrict__ z, const double* __restrict__ m,
+                                 double G, double* __restrict__ sx, double* __restrict__ sy,
+                                 double* __restrict__ sz, double* __restrict__ sgm) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npad) return;
+    const int i = order[p < n ? p : n - 1];
+    sx[p] = x[i];
+    sy[p] = y[i];
+    sz[p] = z[i];
+    sgm[p] = (p < n) ? G * m[i] : 0.0;
+}
+
+// A coordinate one box length outside [0, L) is brought back in (x == L becomes 0), so that
+// the cell a particle is binned in and the coordinate the pair loop uses always agree.
+__device__ __forceinline__ double canonical(double x, double L) {
+    x = (x >= L) ? x - L : x;
+    x = (x < 0.0) ? x + L : x;
+    return (x >= L) ? 0.0 : x;
+}
+
+__global__ void k_canonical_positions(int n, const double* __restrict__ x,
+                                      const double* __restrict__ y, const double* __restrict__ z,
+                                      double L, double* __restrict__ cx, double* __restrict__ cy,
+                                      double* __restrict__ cz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cx[i] = canonical(x[i], L);
+    cy[i] = canonical(y[i], L);
+    cz[i] = canonical(z[i], L);
+}
+
+__global__ void k_gather_targets(int n, int npad, const int* __restrict__ order,
+                                 const double* __restrict__ x, const double* __restrict__ y,
+                                 const double* __restrict__ z, double* __restrict__ tx,
+                                 double* __restrict__ ty, double* __restrict__ tz) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npad) return;
+    const int i = order[p < n ? p : n - 1];
+    tx[p] = x[i];
+    ty[p] = y[i];
+    tz[p] = z[i];
+}
+
+// Conservative integer bounding box of each run of SUB sorted sources, in units of
+// L / 2^QBITS: box = {xlo, xhi, ylo, yhi, zlo, zhi, 0, 0} with lo <= true min and
+// hi > true max (one unit of slack each side absorbs the rounding of x * qscale).
+__device__ __forceinline__ int quantize(double x, double qscale) {
+    double q = floor(x * qscale);
+    q = fmin(fmax(q, -1.0e9), 1.0e9);
+    return static_cast<int>(q);
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(WG) k_source_boxes(int npad, const double* __restrict__ sx,
+                                                     const double* __restrict__ sy,
+                                                     const double* __restrict__ sz,
+                                                     double qscale, int* __restrict__ box) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;  // npad is a multiple of WG
+    if (p >= npad) return;
+    const int qx = quantize(sx[p], qscale), qy = quantize(sy[p], qscale),
+              qz = quantize(sz[p], qscale);
+    const int xlo = wave_min(qx) - 1, xhi = wave_max(qx) + 2;
+    const int ylo = wave_min(qy) - 1, yhi = wave_max(qy) + 2;
+    const int zlo = wave_min(qz) - 1, zhi = wave_max(qz) + 2;
+    if ((threadIdx.x & 63) == 0) {
+        int* b = box + (p >> 6) * 8;
+        b[0] = xlo; b[1] = xhi; b[2] = ylo; b[3] = yhi; b[4] = zlo; b[5] = zhi;
+        b[6] = 0; b[7] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The pair kernel.
+//
+// One workgroup = 4 wavefronts.  Each lane keeps I targets in registers (position +
+// three accumulators); a wavefront therefore owns 64*I consecutive sorted targets,
+// a spatially compact group.  Sources stream through LDS in tiles of TJ 32-byte
+// records {x, y, z, G*m}; every lane reads the same record (a broadcast ds_read_b128
+// pair), so the inner loop is VALU work only.  The next tile's global loads are issued
+// before the current tile is consumed (double-buffered LDS, one barrier per tile).
+//
+// Minimum image without per-pair work: for each (wavefront, 64-source sub-tile) the two
+// integer bounding boxes decide, per axis, whether every pair of the two groups has the
+// same image shift (0, +L or -L).  If so the shift is applied once to the wavefront's
+// target coordinates and the pair loop does no wrap at all; otherwise the sub-tile is
+// processed with the reference's per-pair compare/select (src/math_utils.h:11-16).
+// Both give the reference's choice of image for every pair: the classification only
+// accepts a uniform shift when all displacements are at least L/2^20 away from +-L/2.
+//
+//   MODE 0  direct summation, classified tiles
+//   MODE 1  direct summation, per-pair wrap everywhere
+//   MODE 2  P3M pair function over all pairs, per-pair wrap (small n / testing)
+// ---------------------------------------------------------------------------------
+struct PairArgs {
+    const double* sx; const double* sy; const double* sz; const double* sgm;
+    const int* sbox;      // [n_src_pad / SUB][8]
+    int n_src_pad;        // multiple of TJ
+    const double* tx; const double* ty; const double* tz;
+    const int* tperm;     // sorted target -> index into ax/ay/az
+    int n_tgt;
+    int tiles_per_split;  // source tiles per blockIdx.y slice
+    double* ax; double* ay; double* az;       // output (accumulated into) when gridDim.y == 1
+    double* px; double* py; double* pz;       // partial sums [gridDim.y][n_tgt_pad] otherwise
+    int n_tgt_pad;
+    PairConsts k;
+};
+
+template <int I, int MODE, bool SOFT0>
+__global__ void __launch_bounds__(WG) k_pairs(const PairArgs a) {
+    __shared__ __attribute__((aligned(32))) double4 tile[2][TJ];
+    __shared__ int boxes[2][(TJ / SUB) * 8];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int group_base = (blockIdx.x * (WG / 64) + wave) * (64 * I);
+    const PairConsts k = a.k;
+
+    double xi[I], yi[I], zi[I], ax[I], ay[I], az[I];
+    int ilo[3], ihi[3];
+    {
+        int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+#pragma unroll
+        for (int t = 0; t < I; ++t) {
+            int idx = group_base + t * 64 + lane;
+            idx = idx < a.n_tgt ? idx : a.n_tgt - 1;
+            idx = idx < 0 ? 0 : idx;
+            xi[t] = a.tx[idx]; yi[t] = a.ty[idx]; zi[t] = a.tz[idx];
+            ax[t] = 0.0; ay[t] = 0.0; az[t] = 0.0;
+            const int q[3] = {quantize(xi[t], k.qscale), quantize(yi[t], k.qscale),
+                              quantize(zi[t], k.qscale)};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lo[c] = min(lo[c], q[c]); hi[c] = max(hi[c], q[c]); }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ilo[c] = __builtin_amdgcn_readfirstlane(wave_min(lo[c]) - 1);
+            ihi[c] = __builtin_amdgcn_readfirstlane(wave_max(hi[c]) + 2);
+        }
+    }
+
+    const int n_tiles = a.n_src_pad / TJ;
+    const int tile_begin = blockIdx.y * a.tiles_per_split;
+    int tile_end = tile_begin + a.tiles_per_split;
+    tile_end = tile_end < n_tiles ? tile_end : n_tiles;
+
+    // prologue: stage the first tile
+    double4 stage;
+    int stage_box = 0;
+    if (tile_begin < tile_end) {
+        const int p = tile_begin * TJ + threadIdx.x;
+        stage = make_double4(a.sx[p], a.sy[p], a.sz[p], a.sgm[p]);
+        if (threadIdx.x < (TJ / SUB) * 8) stage_box = a.sbox[tile_begin * (TJ / SUB) * 8 + threadIdx.x];
+    }
+
+    for (int t = tile_begin; t < tile_end; ++t) {
+        const int buf = (t - tile_begin) & 1;
+        tile[buf][threadIdx.x] = stage;
+        if (threadIdx.x < (TJ / SUB) * 8) boxes[buf][threadIdx.x] = stage_box;
+        __syncthreads();
+        if (t + 1 < tile_end) {  // prefetch the next tile into registers
+            const int p = (t + 1) * TJ + threadIdx.x;
+            stage = make_double4(a.sx[p], a.sy[p], a.sz[p], a.sgm[p]);
+            if (threadIdx.x < (TJ / SUB) * 8) stage_box = a.sbox[(t + 1) * (TJ / SUB) * 8 + threadIdx.x];
+        }
+
+#pragma unroll 1
+        for (int s = 0; s < TJ / SUB; ++s) {
+            const double4* __restrict__ src = &tile[buf][s * SUB];
+            bool fast = false;
+            double shift[3] = {0.0, 0.0, 0.0};
+            if constexpr (MODE == 0) {
+                fast = true;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int jlo = __builtin_amdgcn_readfirstlane(boxes[buf][s * 8 + 2 * c]);
+                    const int jhi = __builtin_amdgcn_readfirstlane(boxes[buf][s * 8 + 2 * c + 1]);
+                    const int dlo = jlo - ihi[c];  // < every x_j - x_i of the two groups
+                    const int dhi = jhi - ilo[c];  // > every x_j - x_i
+                    if (dhi <= QHALF - 1 && dlo >= -(QHALF - 1)) {
+                        shift[c] = 0.0;            // no pair wraps
+                    } else if (dlo >= QHALF + 1) {
+                        shift[c] = k.L;            // every pair: d - L == x_j - (x_i + L)
+                    } else if (dhi <= -(QHALF + 1)) {
+                        shift[c] = -k.L;           // every pair: d + L == x_j - (x_i - L)
+                    } else {
+                        fast = false;
+                    }
+                }
+            }
+            if (fast) {
+                double xs[I], ys[I], zs[I];
+#pragma unroll
+                for (int u = 0; u < I; ++u) {
+                    xs[u] = xi[u] + shift[0]; ys[u] = yi[u] + shift[1]; zs[u] = zi[u] + shift[2];
+                }
+#pragma unroll 2
+                for (int j = 0; j < SUB; ++j) {
+                    const double4 pj = src[j];
+#pragma unroll
+                    for (int u = 0; u < I; ++u)
+                        pair_direct<SOFT0>(pj.x - xs[u], pj.y - ys[u], pj.z - zs[u], pj.w, k.eps2,
+                                           ax[u], ay[u], az[u]);
+                }
+            } else {
+#pragma unroll 2
+                for (int j = 0; j < SUB; ++j) {
+                    const double4 pj = src[j];
+#pragma unroll
+                    for (int u = 0; u < I; ++u) {
+                        const double dx = min_image(pj.x - xi[u], k.L, k.half_L);
+                        const double dy = min_image(pj.y - yi[u], k.L, k.half_L);
+                        const double dz = min_image(pj.z - zi[u], k.L, k.half_L);
+                        if constexpr (MODE == 2)
+                            pair_p3m(dx, dy, dz, pj.w, k, ax[u], ay[u], az[u]);
+                        else
+                            pair_direct<SOFT0>(dx, dy, dz, pj.w, k.eps2, ax[u], ay[u], az[u]);
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: scatter to the caller's order, or store this slice's partial sums
+#pragma unroll
+    for (int t = 0; t < I; ++t) {
+        const int idx = group_base + t * 64 + lane;
+        if (idx < a.n_tgt) {
+            if (gridDim.y == 1) {
+                const int o = a.tperm[idx];
+                a.ax[o] += ax[t]; a.ay[o] += ay[t]; a.az[o] += az[t];
+            } else {
+                const size_t o = static_cast<size_t>(blockIdx.y) * a.n_tgt_pad + idx;
+                a.px[o] = ax[t]; a.py[o] = ay[t]; a.pz[o] = az[t];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// P3M short range over a cell list.
+//
+// Sources are counting-sorted by the cells of a search grid (x fastest, as the reference's
+// cell id, src/particles.cpp:94) whose cell size c satisfies R*c >= cutoff radius, so all
+// partners of a target lie in the (2R+1)^3 cells around its own cell
+// (the reference's sweep: src/particles.cpp:187-197 / :287-297 with
+// R = ceil(CUTOFF_RADIUS / CELL_SIZE), :134-137).  Because x is the fastest cell index,
+// the 2R+1 cells of one (dy, dz) row are one contiguous run of the sorted arrays.
+//
+// One lane per target; lanes of a wavefront are consecutive sorted targets, i.e. spatial
+// neighbours walking nearly the same runs (their loads share cache lines).
+//
+// Minimum image: the grid has at least 2R+3 cells per side, so (R+1)*c < L/2 and the image
+// implied by the cell wrap is the reference's minimum image.  The shift is applied to the
+// lane's target coordinate once per run, not per pair.
+// ---------------------------------------------------------------------------------
+struct P3MArgs {
+    const double* sx; const double* sy; const double* sz; const double* sgm;
+    const int* cell_start;   // [nside^3 + 1]
+    int nside;
+    int R;
+    double cell_scale;       // nside / L
+    const double* tx; const double* ty; const double* tz;
+    const int* tperm;
+    int n_tgt;
+    double* ax; double* ay; double* az;
+    unsigned long long* accepted;   // optional counter of pairs with r^2 <= cutoff_sq
+    PairConsts k;
+};
+
+__device__ __forceinline__ void p3m_run(const P3MArgs& a, int jb, int je, double xs, double ys,
+                                        double zs, double& ax, double& ay, double& az,
+                                        unsigned& hits) {
+    for (int j = jb; j < je; ++j) {
+        const double dx = a.sx[j] - xs, dy = a.sy[j] - ys, dz = a.sz[j] - zs;
+        const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+        if (r2 > a.k.cutoff_sq) continue;
+        ++hits;
+        double f = inv_cube_root2_guarded(r2 + a.k.eps2) - inv_cube_root2_guarded(r2 + a.k.eps_pm2);
+        if (r2 > a.k.r_switch_sq) {
+            const double dist = r2 * inv_sqrt_refined(r2);
+            const double t = (dist - a.k.r_switch) * a.k.inv_width;
+            f *= __builtin_fma(t * t, __builtin_fma(2.0, t, -3.0), 1.0);
+        }
+        const double s = a.sgm[j] * f;
+        ax = __builtin_fma(s, dx, ax);
+        ay = __builtin_fma(s, dy, ay);
+        az = __builtin_fma(s, dz, az);
+    }
+}
+
+__global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
+    const int p = blockIdx.x * WG + threadIdx.x;
+    const bool live = p < a.n_tgt;
+    const int pc = live ? p : a.n_tgt - 1;
+    const double xi = a.tx[pc], yi = a.ty[pc], zi = a.tz[pc];
+    const int n = a.nside, R = a.R;
+    const double L = a.k.L;
+    const int cx = bin_coord(xi, a.cell_scale, n), cy = bin_coord(yi, a.cell_scale, n),
+              cz = bin_coord(zi, a.cell_scale, n);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    unsigned hits = 0;
+    if (live) {
+        for (int oz = -R; oz <= R; ++oz) {
+            int z2 = cz + oz;
+            double zs = zi;
+            if (z2 < 0) { z2 += n; zs = zi + L; } else if (z2 >= n) { z2 -= n; zs = zi - L; }
+            for (int oy = -R; oy <= R; ++oy) {
+                int y2 = cy + oy;
+                double ys = yi;
+                if (y2 < 0) { y2 += n; ys = yi + L; } else if (y2 >= n) { y2 -= n; ys = yi - L; }
+                const int row = (z2 * n + y2) * n;
+                const int x0 = cx - R, x1 = cx + R;
+                const int m0 = x0 < 0 ? 0 : x0, m1 = x1 >= n ? n - 1 : x1;
+                p3m_run(a, a.cell_start[row + m0], a.cell_start[row + m1 + 1], xi, ys, zs, ax, ay, az, hits);
+                if (x0 < 0)   // sources in the top cells seen one box length lower
+                    p3m_run(a, a.cell_start[row + x0 + n], a.cell_start[row + n], xi + L, ys, zs, ax, ay, az, hits);
+                if (x1 >= n)  // sources in the bottom cells seen one box length higher
+                    p3m_run(a, a.cell_start[row], a.cell_start[row + x1 - n + 1], xi - L, ys, zs, ax, ay, az, hits);
+            }
+        }
+        const int o = a.tperm[p];
+        a.ax[o] += ax; a.ay[o] += ay; a.az[o] += az;
+    }
+    if (a.accepted) {
+        unsigned long long h = live ? hits - 1u : 0u;  // minus the target's own zero-distance entry
+        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        if ((threadIdx.x & 63) == 0 && h) atomicAdd(a.accepted, h);
+    }
+}
+
+// Sum the per-slice partials in slice order (deterministic) and accumulate into the output.
+__global__ void k_reduce_partials(int n_tgt, int n_tgt_pad, int n_split,
+                                  const double* __restrict__ px, const double* __restrict__ py,
+                                  const double* __restrict__ pz, const int* __restrict__ tperm,
+                                  double* __restrict__ ax, double* __restrict__ ay,
+                                  double* __restrict__ az) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_tgt) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int s = 0; s < n_split; ++s) {
+        const size_t o = static_cast<size_t>(s) * n_tgt_pad + idx;
+        sx += px[o]; sy += py[o]; sz += pz[o];
+    }
+    const int o = tperm[idx];
+    ax[o] += sx; ay[o] += sy; az[o] += sz;
+}
+
+// ---------------------------------------------------------------------------------
+// Caller-contract kernels: HBM-bandwidth-bound streams.
+// ---------------------------------------------------------------------------------
+// v += a*(dt/a^3) - v*(2 H dt)                                   src/integrator.cpp:168-181
+__global__ void k_kick(size_t n, double* __restrict__ vx, double* __restrict__ vy,
+                       double* __restrict__ vz, const double* __restrict__ ax,
+                       const double* __restrict__ ay, const double* __restrict__ az,
+                       double dt_over_a3, double dt_2H) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        // two roundings per product and one per add/sub, like the reference's statement
+        vx[i] = vx[i] + (__dmul_rn(ax[i], dt_over_a3) - __dmul_rn(vx[i], dt_2H));
+        vy[i] = vy[i] + (__dmul_rn(ay[i], dt_over_a3) - __dmul_rn(vy[i], dt_2H));
+        vz[i] = vz[i] + (__dmul_rn(az[i], dt_over_a3) - __dmul_rn(vz[i], dt_2H));
+    }
+}
+
+// x += v*dt ; x -= L*floor(x/L)                                  src/integrator.cpp:183-198
+__global__ void k_drift(size_t n, double* __restrict__ x, double* __restrict__ y,
+                        double* __restrict__ z, const double* __restrict__ vx,
+                        const double* __restrict__ vy, const double* __restrict__ vz, double dt,
+                        double L, double inv_L) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double nx = __dadd_rn(x[i], __dmul_rn(vx[i], dt));
+        const double ny = __dadd_rn(y[i], __dmul_rn(vy[i], dt));
+        const double nz = __dadd_rn(z[i], __dmul_rn(vz[i], dt));
+        x[i] = __dsub_rn(nx, __dmul_rn(L, floor(__dmul_rn(nx, inv_L))));
+        y[i] = __dsub_rn(ny, __dmul_rn(L, floor(__dmul_rn(ny, inv_L))));
+        z[i] = __dsub_rn(nz, __dmul_rn(L, floor(__dmul_rn(nz, inv_L))));
+    }
+}
+
+// max_i (ax^2 + ay^2 + az^2), per-block partial maxima              src/integrator.cpp:200-213
+__global__ void __launch_bounds__(WG) k_max_accel_sq(size_t n, const double* __restrict__ ax,
+                                                     const double* __restrict__ ay,
+                                                     const double* __restrict__ az,
+                                                     double* __restrict__ block_max) {
+    __shared__ double lds[WG / 64];
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    double m = 0.0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double s = __dadd_rn(__dadd_rn(__dmul_rn(ax[i], ax[i]), __dmul_rn(ay[i], ay[i])),
+                                   __dmul_rn(az[i], az[i]));
+        m = (s > m) ? s : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double o = __shfl_xor(m, d, 64);
+        m = (o > m) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < WG / 64; ++w) m = (lds[w] > m) ? lds[w] : m;
+        block_max[blockIdx.x] = m;
+    }
+}
+
+__global__ void k_fill_int(int n, int* p, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void k_iota(int n, int* p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+}  // namespace nbpp

@@ -1,0 +1,157 @@
+"""ctypes binding of libnbpp.so, one Python method per entry point of include/nbpp.h."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libnbpp.so")
+
+KERNEL_NONE, KERNEL_DIRECT, KERNEL_DIRECT_WRAP, KERNEL_P3M_CELLS, KERNEL_P3M_ALLPAIRS = range(5)
+OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SEARCH_RADIUS = \
+    1, 2, 3, 4, 5
+
+EXPORTS = (
+    "nbpp_init", "nbpp_shutdown", "nbpp_last_error", "nbpp_set_option", "nbpp_get_stats",
+    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_kick_device", "nbpp_drift_device",
+    "nbpp_max_accel_sq_device",
+)
+
+
+class NbppError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libnbpp error {code}: {message}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """nbpp_params: the scalars hoisted at reference src/particles.cpp:134-152."""
+    _fields_ = [(k, C.c_double) for k in (
+        "domain_size", "G", "soft_sq", "pm_soft_sq", "r_switch", "r_switch_sq",
+        "cutoff_sq", "trans_width", "cell_size")] + [("mesh_size", C.c_int32),
+                                                     ("use_pm", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("pair_kernel_ms", "prepare_ms", "total_ms",
+                                          "h2d_ms", "d2h_ms")] + [
+        (k, C.c_uint64) for k in ("n_sources", "n_targets", "pairs_evaluated",
+                                  "pairs_accepted", "pair_launches")] + [
+        ("kernel_variant", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_DP = C.POINTER(C.c_double)
+
+
+def _host(a):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+        raise TypeError("host arrays must be C-contiguous float64 numpy arrays")
+    return a.ctypes.data_as(_DP)
+
+
+def _dev(t):
+    """Device pointer of a torch CUDA float64 tensor (torch is only plumbing here)."""
+    if t.dtype.__str__() != "torch.float64" or not t.is_cuda or not t.is_contiguous():
+        raise TypeError("device arrays must be contiguous float64 CUDA tensors")
+    return C.cast(C.c_void_p(t.data_ptr()), _DP)
+
+
+class Library:
+    """Loaded libnbpp.so.  Construction fails loudly when the shared object is missing."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it with `make -C nbody_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path")
+        L = self.lib = C.CDLL(path)
+        self.path = path
+        L.nbpp_init.argtypes = [C.c_int]
+        L.nbpp_shutdown.restype = None
+        L.nbpp_last_error.restype = C.c_char_p
+        L.nbpp_set_option.argtypes = [C.c_int, C.c_int64]
+        L.nbpp_get_stats.argtypes = [C.POINTER(Stats)]
+        L.nbpp_accumulate.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7
+        L.nbpp_accumulate_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 4 + [
+            C.c_size_t, C.c_size_t] + [_DP] * 3 + [C.c_void_p]
+        L.nbpp_kick_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 3 + [C.c_void_p]
+        L.nbpp_drift_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 2 + [C.c_void_p]
+        L.nbpp_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
+        self._inited = False
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NbppError(rc, self.lib.nbpp_last_error().decode(errors="replace"))
+
+    # lifecycle -------------------------------------------------------------------
+    def init(self, device=-1):
+        self._check(self.lib.nbpp_init(device))
+        self._inited = True
+        return self
+
+    def shutdown(self):
+        self.lib.nbpp_shutdown()
+        self._inited = False
+
+    def set_option(self, key, value):
+        self._check(self.lib.nbpp_set_option(key, int(value)))
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.nbpp_get_stats(C.byref(s)))
+        return s.as_dict()
+
+    # hot path --------------------------------------------------------------------
+    def accumulate(self, p, x, y, z, m, ax, ay, az):
+        """Host numpy arrays; ax/ay/az are accumulated into (nbpp_accumulate)."""
+        n = x.size
+        self._check(self.lib.nbpp_accumulate(C.byref(p), n, _host(x), _host(y), _host(z),
+                                             _host(m), _host(ax), _host(ay), _host(az)))
+
+    def accumulate_device(self, p, x, y, z, m, ax, ay, az, tgt_begin=0, n_tgt=None,
+                          stream=None):
+        """torch CUDA tensors (nbpp_accumulate_device)."""
+        n_src = x.numel()
+        if n_tgt is None:
+            n_tgt = n_src - tgt_begin
+        if ax.numel() < n_tgt:
+            raise ValueError("acceleration arrays shorter than the target count")
+        self._check(self.lib.nbpp_accumulate_device(
+            C.byref(p), n_src, _dev(x), _dev(y), _dev(z), _dev(m), tgt_begin, n_tgt,
+            _dev(ax), _dev(ay), _dev(az), C.c_void_p(stream or 0)))
+
+    # caller contract ---------------------------------------------------------------
+    def kick_device(self, v, a, dt, scale_factor, hubble, stream=None):
+        self._check(self.lib.nbpp_kick_device(v[0].numel(), _dev(v[0]), _dev(v[1]), _dev(v[2]),
+                                              _dev(a[0]), _dev(a[1]), _dev(a[2]), dt,
+                                              scale_factor, hubble, C.c_void_p(stream or 0)))
+
+    def drift_device(self, x, v, dt, domain_size, stream=None):
+        self._check(self.lib.nbpp_drift_device(x[0].numel(), _dev(x[0]), _dev(x[1]), _dev(x[2]),
+                                               _dev(v[0]), _dev(v[1]), _dev(v[2]), dt,
+                                               domain_size, C.c_void_p(stream or 0)))
+
+    def max_accel_sq_device(self, a, stream=None):
+        out = C.c_double(0.0)
+        self._check(self.lib.nbpp_max_accel_sq_device(a[0].numel(), _dev(a[0]), _dev(a[1]),
+                                                      _dev(a[2]), C.byref(out),
+                                                      C.c_void_p(stream or 0)))
+        return out.value
+
+
+_LIB = None
+
+
+def load(device=None):
+    """Process-wide Library; `device` given -> also nbpp_init(device)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Library()
+    if device is not None and not _LIB._inited:
+        _LIB.init(device)
+    return _LIB

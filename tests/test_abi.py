@@ -1,0 +1,56 @@
+"""The C-ABI library loads on a CPU-only machine and exports what include/nbpp.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nbody_amd
+from nbody_amd import ffi
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "nbpp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nbpp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree():
+    names = _declared()
+    assert len(names) >= 10
+    lib = ctypes.CDLL(ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nbpp.h but not exported"
+    assert sorted(ffi.EXPORTS) == names
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(ffi.Params) == 9 * 8 + 2 * 4
+    assert ctypes.sizeof(ffi.Stats) == 5 * 8 + 5 * 8 + 2 * 4
+    from oracle.oracle import Params as OrcParams
+    assert [f[0] for f in OrcParams._fields_] == [f[0] for f in ffi.Params._fields_]
+
+
+def test_no_silent_fallback_without_gpu():
+    """Without a GPU every compute entry point must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = ffi.Library()
+    with pytest.raises(ffi.NbppError):
+        L.init(0)
+    p = nbody_amd.Config().pp_params()
+    a = np.zeros(4)
+    with pytest.raises(ffi.NbppError) as e:
+        L.accumulate(p, a, a, a, a, a.copy(), a.copy(), a.copy())
+    assert e.value.code == -3  # NBPP_ERR_NOINIT
+
+
+def test_product_does_not_import_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "nbody_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "oracle" not in text.lower().replace("test_oracle", ""), f

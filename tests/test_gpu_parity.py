@@ -1,0 +1,387 @@
+"""GPU parity: libnbpp (through its C ABI) against the CPU oracle and the golden vectors.
+
+Tolerance for every force comparison: max_i,c |a_gpu - a_ref|_c / ||a_ref,i||_2 <= 1e-10
+(fp64; two correct summation orders already differ at the 1e-12 level).  Integer results
+(accepted-pair counts) and the kick / drift / max kernels are compared exactly.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, normalised_error, pair_force_scale
+from nbody_amd import Config, ParticleSystem, ffi
+from oracle import oracle as O
+import datasets
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def gpu_acc(lib, p, pos, m, acc0=None):
+    acc = [np.zeros(m.size) if acc0 is None else a.copy() for a in (acc0 or [None] * 3)]
+    lib.accumulate(p, pos[0], pos[1], pos[2], m, *acc)
+    return acc
+
+
+# --------------------------------------------------------------------------------------
+# the reference's own known-answer tests, written against the mirrored interface
+# --------------------------------------------------------------------------------------
+def _two_body(lib):
+    config = Config()
+    config.MESH_SIZE = 4
+    config.CELL_SIZE = 2.0
+    config.DOMAIN_SIZE = 8.0
+    config.NUM_DM_PARTICLES = 2
+    config.G = 1.0
+    config.SOFTENING_SQUARED = 0.0
+    sys_ = ParticleSystem(config, lib)
+    sys_.add_particle(2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 1.0)
+    sys_.add_particle(5.0, 2.0, 2.0, 0.0, 0.0, 0.0, 1.0)
+    return config, sys_
+
+
+def test_kat_pure_newtonian_pp(lib):
+    """tests/test_gravity.cpp:115-134."""
+    config, sys_ = _two_body(lib)
+    config.USE_PM = False
+    config.CUTOFF_RADIUS_SQUARED = (config.DOMAIN_SIZE / 2.0) ** 2
+    sys_.bin_and_assign_mass(config)
+    sys_.compute_pp_forces(config)
+    expected_f = 1.0 / 9.0
+    assert sys_.acc_x[0] == pytest.approx(expected_f, rel=1e-14)
+    assert sys_.acc_y[0] == 0.0 and sys_.acc_z[0] == 0.0
+    assert sys_.acc_x[1] == pytest.approx(-expected_f, rel=1e-14)
+
+
+def test_kat_p3m_cutoff_ignores_distant(lib):
+    """tests/test_gravity.cpp:136-154."""
+    config, sys_ = _two_body(lib)
+    config.USE_PM = True
+    config.CUTOFF_RADIUS = 2.0
+    config.CUTOFF_RADIUS_SQUARED = 4.0
+    config.R_SWITCH_START = 1.0
+    config.R_SWITCH_START_SQ = 1.0
+    config.CUTOFF_TRANSITION_WIDTH = 1.0
+    sys_.bin_and_assign_mass(config)
+    sys_.acc_x[:] = 0.0
+    sys_.compute_pp_forces(config)
+    assert sys_.acc_x[0] == 0.0 and sys_.acc_x[1] == 0.0
+
+
+def test_kat_wrap_cases_through_the_kernel(lib, oracle):
+    """tests/test_math.cpp:14-47 exercised end to end: two bodies 62, 2 and 32 apart in a box
+    of 64 must attract along the shortest path."""
+    config = Config(DOMAIN_SIZE=64.0, MESH_SIZE=8, N_PER_SIDE=2, USE_PM=False)
+    p = config.pp_params()
+    for xa, xb, sign in ((1.0, 63.0, -1.0), (32.0, 30.0, -1.0), (10.0, 42.0, +1.0)):
+        pos = [np.array([xa, xb]), np.array([5.0, 5.0]), np.array([7.0, 7.0])]
+        m = np.array([1.0, 1.0])
+        got = gpu_acc(lib, p, pos, m)
+        want = oracle.accumulate(p, *pos, m)
+        assert np.sign(got[0][0]) == sign
+        assert normalised_error(got, want) < TOL
+
+
+# --------------------------------------------------------------------------------------
+# golden vectors (independent long-double sums)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lattice8", "lattice12_even_exact", "uniform1000",
+                                  "clustered1500"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_golden_small_sets(lib, name, mode):
+    g = np.load(os.path.join(GOLDEN, "pp_small.npz"))
+    pos = [np.ascontiguousarray(c) for c in g[f"{name}_pos"]]
+    m, want = g[f"{name}_mass"], g[f"{name}_acc_mode{mode}"]
+    pv = g[f"{name}_params_mode{mode}"]
+    p = ffi.Params(*pv[:9], int(pv[9]), int(pv[10]))
+    got = gpu_acc(lib, p, pos, m)
+    floor = pair_force_scale(p, m, m.size) if "exact" in name else 0.0
+    assert normalised_error(got, want, floor) < TOL
+
+
+# --------------------------------------------------------------------------------------
+# direct summation vs the oracle
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [ffi.KERNEL_DIRECT, ffi.KERNEL_DIRECT_WRAP])
+@pytest.mark.parametrize("per_lane", [1, 2, 4])
+def test_direct_variants(lib, oracle, variant, per_lane):
+    pos = datasets.jittered_lattice(16)
+    m = datasets.masses(4096)
+    p = Config(MESH_SIZE=16, N_PER_SIDE=16, USE_PM=False).pp_params()
+    want = oracle.accumulate(p, *pos, m)
+    lib.set_option(ffi.OPT_FORCE_KERNEL, variant)
+    lib.set_option(ffi.OPT_TARGETS_PER_LANE, per_lane)
+    try:
+        got = gpu_acc(lib, p, pos, m)
+        assert lib.stats()["kernel_variant"] == variant
+    finally:
+        lib.set_option(ffi.OPT_FORCE_KERNEL, 0)
+        lib.set_option(ffi.OPT_TARGETS_PER_LANE, 0)
+    assert normalised_error(got, want) < TOL
+
+
+@pytest.mark.parametrize("split", [1, 3, 16])
+def test_direct_source_split_is_deterministic(lib, oracle, split):
+    pos = datasets.clustered(5000)
+    m = datasets.masses(5000, equal=False)
+    p = Config(MESH_SIZE=16, N_PER_SIDE=17, USE_PM=False).pp_params()
+    want = oracle.accumulate(p, *pos, m)
+    lib.set_option(ffi.OPT_SOURCE_SPLIT, split)
+    try:
+        a = gpu_acc(lib, p, pos, m)
+        b = gpu_acc(lib, p, pos, m)
+    finally:
+        lib.set_option(ffi.OPT_SOURCE_SPLIT, 0)
+    assert normalised_error(a, want) < TOL
+    for c in range(3):
+        assert np.array_equal(a[c], b[c])  # bitwise reproducible from run to run
+
+
+@pytest.mark.parametrize("L", [1.0, 64.0, 10.0, 0.3])
+def test_direct_box_sizes(lib, oracle, L):
+    """Power-of-two and other box lengths: the image choice must be the reference's."""
+    pos = datasets.uniform_random(3001, L=L)
+    m = datasets.masses(3001, equal=False)
+    p = Config(DOMAIN_SIZE=L, MESH_SIZE=9, N_PER_SIDE=14, USE_PM=False).pp_params()
+    assert normalised_error(gpu_acc(lib, p, pos, m), oracle.accumulate(p, *pos, m)) < TOL
+
+
+def test_direct_32cubed_full(lib, oracle):
+    """BASELINE config 1 size: 32^3 particles, PP only, every ordered pair."""
+    pos = datasets.jittered_lattice(32)
+    m = datasets.masses(32768)
+    p = Config(MESH_SIZE=32, N_PER_SIDE=32, USE_PM=False).pp_params()
+    want = oracle.accumulate(p, *pos, m)
+    got = gpu_acc(lib, p, pos, m)
+    assert normalised_error(got, want) < TOL
+    st = lib.stats()
+    assert st["pairs_evaluated"] == 32768 * 32767
+
+
+def test_half_box_pairs_on_perfect_lattice(lib, oracle):
+    """Even lattice, no jitter: a whole plane of partners sits at |d| == L/2 or one ulp off,
+    where the reference leaves +-L/2 unwrapped (src/math_utils.h:13-14).  Forces there are
+    O(1e-2) with a sign that depends on that choice."""
+    for n_side in (8, 12, 16):
+        pos = datasets.jittered_lattice(n_side, jitter=0.0)
+        m = datasets.masses(n_side ** 3)
+        p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=False).pp_params()
+        want = oracle.accumulate(p, *pos, m)
+        got = gpu_acc(lib, p, pos, m)
+        assert np.max(np.abs(want[0])) > 1e-3
+        assert normalised_error(got, want, pair_force_scale(p, m, m.size)) < TOL
+
+
+def test_positions_on_the_faces(lib, oracle):
+    """Particles at 0, at the last double below L and at L itself (the drift can produce
+    x == L, src/integrator.cpp:194)."""
+    pos = datasets.uniform_random(600)
+    for c in range(3):
+        pos[c][:4] = [0.0, np.nextafter(1.0, 0.0), 1.0, 0.5]
+    m = datasets.masses(600)
+    for use_pm in (False, True):
+        p = Config(MESH_SIZE=8, N_PER_SIDE=8, USE_PM=use_pm).pp_params()
+        assert normalised_error(gpu_acc(lib, p, pos, m), oracle.accumulate(p, *pos, m)) < TOL
+
+
+def test_accumulates_into_existing_acc(lib, oracle):
+    """acc += sum (src/particles.cpp:362-364), not acc = sum."""
+    pos = datasets.uniform_random(777)
+    m = datasets.masses(777)
+    p = Config(MESH_SIZE=8, N_PER_SIDE=9, USE_PM=False).pp_params()
+    rng = np.random.default_rng(1)
+    acc0 = [rng.standard_normal(777) for _ in range(3)]
+    want = oracle.accumulate(p, *pos, m, acc=[a.copy() for a in acc0])
+    got = gpu_acc(lib, p, pos, m, acc0)
+    assert normalised_error(got, want) < TOL
+    assert np.max(np.abs(got[0] - acc0[0])) > 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 1023])
+def test_ragged_sizes(lib, oracle, n):
+    pos = datasets.uniform_random(n, seed=n)
+    m = datasets.masses(n, equal=False, seed=n)
+    for use_pm in (False, True):
+        p = Config(MESH_SIZE=8, N_PER_SIDE=4, USE_PM=use_pm).pp_params()
+        got = gpu_acc(lib, p, pos, m)
+        want = oracle.accumulate(p, *pos, m)
+        assert normalised_error(got, want) < TOL
+
+
+def test_empty_input_and_errors(lib):
+    p = Config(USE_PM=False).pp_params()
+    e = np.zeros(0)
+    lib.accumulate(p, e, e, e, e, e.copy(), e.copy(), e.copy())  # n == 0: no-op, no error
+    a = np.zeros(8)
+    bad = Config(USE_PM=False).pp_params()
+    bad.domain_size = -1.0
+    with pytest.raises(ffi.NbppError) as err:
+        lib.accumulate(bad, a, a, a, a, a.copy(), a.copy(), a.copy())
+    assert err.value.code == -1
+    import ctypes as C
+    rc = lib.lib.nbpp_accumulate(C.byref(p), 8, None, None, None, None, None, None, None)
+    assert rc == -1 and b"NULL" in lib.lib.nbpp_last_error()
+    with pytest.raises(ffi.NbppError):
+        lib.set_option(999, 1)
+
+
+def test_zero_softening_coincident_and_self(lib, oracle):
+    """SOFTENING_SQUARED == 0: the self pair is excluded (src/particles.cpp:202,302)."""
+    pos = datasets.uniform_random(500)
+    m = datasets.masses(500)
+    p = Config(MESH_SIZE=8, N_PER_SIDE=8, USE_PM=False).pp_params()
+    p.soft_sq = 0.0
+    got = gpu_acc(lib, p, pos, m)
+    assert np.all(np.isfinite(got[0]))
+    assert normalised_error(got, oracle.accumulate(p, *pos, m)) < TOL
+
+
+# --------------------------------------------------------------------------------------
+# P3M short range
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [ffi.KERNEL_P3M_CELLS, ffi.KERNEL_P3M_ALLPAIRS])
+@pytest.mark.parametrize("n_side", [16, 24])
+def test_p3m_vs_oracle(lib, oracle, variant, n_side):
+    pos = datasets.jittered_lattice(n_side)
+    m = datasets.masses(n_side ** 3)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True).pp_params()
+    want = oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS)
+    lib.set_option(ffi.OPT_FORCE_KERNEL, variant)
+    try:
+        got = gpu_acc(lib, p, pos, m)
+        st = lib.stats()
+    finally:
+        lib.set_option(ffi.OPT_FORCE_KERNEL, 0)
+    assert st["kernel_variant"] == variant
+    assert normalised_error(got, want) < TOL
+    if variant == ffi.KERNEL_P3M_CELLS:
+        assert st["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)  # exact integer
+
+
+@pytest.mark.parametrize("radius", [1, 2, 3, 4])
+def test_p3m_search_grid_choices(lib, oracle, radius):
+    pos = datasets.clustered(20000)
+    m = datasets.masses(20000, equal=False)
+    p = Config(MESH_SIZE=32, N_PER_SIDE=27, USE_PM=True).pp_params()
+    want = oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS)
+    lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, radius)
+    try:
+        got = gpu_acc(lib, p, pos, m)
+        st = lib.stats()
+    finally:
+        lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, 0)
+    assert st["kernel_variant"] == ffi.KERNEL_P3M_CELLS
+    assert normalised_error(got, want) < TOL
+    assert st["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
+
+
+def test_p3m_default_ini_32cubed(lib, oracle):
+    """The shipped simulation.ini geometry: 32^3 particles, mesh 32, cutoff 2.5 cells."""
+    ref = json.load(open(os.path.join(GOLDEN, "reference_config.json")))["simulation_ini"]
+    pos = datasets.jittered_lattice(32)
+    m = np.full(32768, ref["dm_particle_mass"])
+    config = Config(OMEGA_BARYON=ref["omega_baryon"])
+    assert config.G == ref["G"] and config.SOFTENING_SQUARED == ref["softening_squared"]
+    p = config.pp_params()
+    want = oracle.accumulate(p, *pos, m, traversal=O.REF_CPU)  # the reference's CPU branch
+    got = gpu_acc(lib, p, pos, m)
+    assert normalised_error(got, want) < TOL
+    per = lib.stats()["pairs_accepted"] / 32768
+    assert 60 < per < 80
+
+
+def test_p3m_wide_taper_other_box(lib, oracle):
+    ref = json.load(open(os.path.join(GOLDEN, "reference_config.json")))["box10_wide"]
+    pos = datasets.clustered(9000, L=10.0)
+    m = datasets.masses(9000, equal=False)
+    config = Config(DOMAIN_SIZE=10.0, MESH_SIZE=20, N_PER_SIDE=12, CUTOFF_RADIUS_CELLS=3.0,
+                    CUTOFF_TRANSITION_WIDTH_FACTOR=0.35)
+    assert config.R_SWITCH_START == ref["r_switch_start"]
+    p = config.pp_params()
+    assert normalised_error(gpu_acc(lib, p, pos, m),
+                            oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS)) < TOL
+
+
+# --------------------------------------------------------------------------------------
+# device-resident entry points
+# --------------------------------------------------------------------------------------
+def _t(arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+@pytest.mark.parametrize("use_pm", [False, True])
+def test_device_entry_target_slices(lib, oracle, use_pm):
+    """The i-partition of a multi-GPU run: all sources, a slice of targets."""
+    import torch
+    n = 6000
+    pos = datasets.clustered(n)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=24, N_PER_SIDE=18, USE_PM=use_pm).pp_params()
+    want = oracle.accumulate(p, *pos, m)
+    x, y, z, mm = _t(pos + [m])
+    pieces = [[], [], []]
+    for begin, count in ((0, 1500), (1500, 1), (1501, 2999), (4500, 1500)):
+        acc = [torch.zeros(count, dtype=torch.float64, device="cuda") for _ in range(3)]
+        lib.accumulate_device(p, x, y, z, mm, *acc, tgt_begin=begin, n_tgt=count)
+        torch.cuda.synchronize()
+        for c in range(3):
+            pieces[c].append(acc[c].cpu().numpy())
+    got = [np.concatenate(pc) for pc in pieces]
+    assert normalised_error(got, want) < TOL
+
+
+def test_kick_drift_max_exact(lib, oracle):
+    import torch
+    rng = np.random.default_rng(2)
+    n = 100003
+    v = [rng.standard_normal(n) for _ in range(3)]
+    a = [rng.standard_normal(n) * 1e-2 for _ in range(3)]
+    x = [rng.random(n) for _ in range(3)]
+    tv, ta, tx = _t(v), _t(a), _t(x)
+    dt, sc, H = 4.3e-3, 0.02, 235.7
+    lib.kick_device(tv, ta, dt / 2, sc, H)
+    lib.drift_device(tx, tv, dt, 1.0)
+    mx = lib.max_accel_sq_device(ta)
+    torch.cuda.synchronize()
+    oracle.kick(v, a, dt / 2, sc, H)
+    oracle.drift(x, v, dt, 1.0)
+    for c in range(3):
+        assert np.array_equal(tv[c].cpu().numpy(), v[c])
+        assert np.array_equal(tx[c].cpu().numpy(), x[c])
+    assert mx == oracle.max_accel_sq(a)
+    tiny = _t([np.full(10, 1e-6)] * 3)
+    assert lib.max_accel_sq_device(tiny) == 1e-9
+
+
+# --------------------------------------------------------------------------------------
+# full-size properties (BASELINE config 2 size, sampled)
+# --------------------------------------------------------------------------------------
+def test_128cubed_sampled_targets_and_momentum(lib, oracle):
+    """N = 128^3 direct sum on the GPU: 48 sampled targets against the oracle's exact sum over
+    all 2.1 M sources, and total momentum change sum_i m_i a_i == 0 (Newton's third law, which
+    the kernel never uses explicitly)."""
+    import torch
+    n_side = 128
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side)
+    m = datasets.masses(n)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=False).pp_params()
+    x, y, z, mm = _t(pos + [m])
+    acc = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    lib.accumulate_device(p, x, y, z, mm, *acc)
+    torch.cuda.synchronize()
+    got = [a.cpu().numpy() for a in acc]
+    rng = np.random.default_rng(4)
+    sample = np.sort(rng.choice(n, 48, replace=False))
+    want = [np.zeros(48) for _ in range(3)]
+    for k, i in enumerate(sample):  # one target at a time through the slice interface
+        w = oracle.accumulate(p, *pos, m, tgt_begin=int(i), n_tgt=1)
+        for c in range(3):
+            want[c][k] = w[c][0]
+    assert normalised_error([g[sample] for g in got], want) < TOL
+    typical = np.mean(np.sqrt(got[0] ** 2 + got[1] ** 2 + got[2] ** 2)) * m[0] * n
+    for c in range(3):
+        assert abs(np.sum(m * got[c])) < 1e-9 * typical
