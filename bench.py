@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: direct-summation PP gravity, fp64, N = 128^3, on N GPUs of one node.
+
+One step = one force evaluation of the whole particle set: every rank all-gathers the
+positions (RCCL; a no-op on one GPU), then runs the pair kernel for its own slice of targets
+against all sources.  Inputs are resident in HBM before the timed region.  Rank 0 prints one
+JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-side 128] [--mode direct|p3m]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 128 flop/clk x 2.4 GHz
+FLOPS_PER_PAIR_DIRECT = 25       # periodic, softened direct PP (FMA = 2, rsqrt = 1)
+FLOPS_PER_PAIR_P3M = 40          # per accepted P3M pair
+
+
+def cpu_baseline(p, pos, m, mode, budget_s=15.0):
+    """The CPU port (oracle/pp_oracle.c, -O3 AVX2+FMA build, OpenMP on every host core) on a
+    bounded sample of targets of the same workload."""
+    from oracle.oracle import Oracle, EXACT_CELLS, EXACT
+    orc = Oracle(fast=True)
+    n = m.size
+    cores = min(orc.max_threads(), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    if mode == "direct":
+        n_tgt = 64 * cores
+        while True:
+            t0 = time.perf_counter()
+            orc.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=EXACT, nthreads=cores)
+            dt = time.perf_counter() - t0
+            if dt > 0.25 * budget_s or n_tgt * 4 > n:
+                break
+            n_tgt = min(n, int(n_tgt * max(2.0, 0.6 * budget_s / max(dt, 1e-3))))
+        pairs = n_tgt * (n - 1)
+        sample = f"{n_tgt} targets x all {n} sources, {dt:.2f} s"
+    else:
+        n_tgt = n
+        t0 = time.perf_counter()
+        orc.accumulate(p, *pos, m, traversal=EXACT_CELLS, nthreads=cores)
+        dt = time.perf_counter() - t0
+        pairs = orc.count_within_cutoff(p, *pos, nthreads=cores)
+        sample = f"all {n} targets, cell search, {dt:.2f} s"
+    return {"value": pairs / dt / 1e9, "unit": "Ginter/s", "cores": cores, "kind": "port",
+            "sample": sample, "build": "fast" if orc.fast else "strict"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-side", type=int, default=128)
+    ap.add_argument("--mode", choices=["direct", "p3m"], default="direct")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-lane", type=int, default=0)
+    ap.add_argument("--force-kernel", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import nbody_amd
+    from nbody_amd import Config, ffi
+    import datasets
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = nbody_amd.load(device=local_rank)
+    lib.set_option(ffi.OPT_TIMING, 1)
+    lib.set_option(ffi.OPT_TARGETS_PER_LANE, args.per_lane)
+    lib.set_option(ffi.OPT_FORCE_KERNEL, args.force_kernel)
+
+    n_side = args.n_side
+    n = n_side ** 3
+    use_pm = args.mode == "p3m"
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm)
+    p = config.pp_params()
+    pos = datasets.jittered_lattice(n_side)           # same seeded set on every rank
+    m = np.full(n, config.DM_PARTICLE_MASS)
+
+    # i-partition: contiguous, near-equal slices of the particle index range
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    begin = sum(counts[:rank])
+    mine = counts[rank]
+    maxc = max(counts)
+
+    # device-resident state: each rank owns its slice of x, y, z; masses are gathered once
+    own = [torch.zeros(maxc, dtype=torch.float64, device=dev) for _ in range(3)]
+    for c in range(3):
+        own[c][:mine] = torch.from_numpy(pos[c][begin:begin + mine]).to(dev)
+    mass = torch.from_numpy(m).to(dev)
+    full = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3)]
+    gathered = [torch.empty(maxc * world, dtype=torch.float64, device=dev) for _ in range(3)]
+    acc = [torch.zeros(mine, dtype=torch.float64, device=dev) for _ in range(3)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        if world > 1:
+            for c in range(3):
+                dist.all_gather_into_tensor(gathered[c], own[c])
+                if n % world == 0:
+                    full[c] = gathered[c]
+                else:
+                    off = 0
+                    for r in range(world):
+                        full[c][off:off + counts[r]] = gathered[c][r * maxc:r * maxc + counts[r]]
+                        off += counts[r]
+        else:
+            for c in range(3):
+                full[c] = own[c]
+        for a in acc:
+            a.zero_()
+        lib.accumulate_device(p, full[0], full[1], full[2], mass, *acc, tgt_begin=begin,
+                              n_tgt=mine, stream=stream)
+        return lib.stats()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, prep_ms, accepted = [], [], 0
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms.append(st["pair_kernel_ms"])
+        prep_ms.append(st["prepare_ms"])
+        accepted = st["pairs_accepted"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(accepted)], dtype=torch.float64,
+                     device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, kernel_avg_ms, accepted_total = float(tmax[0]), float(tmax[1]), float(tsum[2])
+    else:
+        elapsed, kernel_avg_ms, accepted_total = float(t[0]), float(t[1]), float(t[2])
+
+    if rank == 0:
+        if use_pm:
+            pairs_per_step = accepted_total
+            flops = FLOPS_PER_PAIR_P3M
+            workload = f"P3M short range, {n_side}^3 particles, mesh {n_side}, cutoff 2.5 cells"
+        else:
+            pairs_per_step = float(n) * float(n - 1)
+            flops = FLOPS_PER_PAIR_DIRECT
+            workload = f"PP direct summation fp64, N={n_side}^3, periodic box"
+        value = pairs_per_step * args.steps / elapsed / 1e9
+        # dominant kernel on rank 0's share: algorithmic flops of one launch / its duration
+        my_pairs = pairs_per_step * (counts[0] / n)
+        achieved = my_pairs * flops / (kernel_avg_ms * 1e-3) / 1e12
+        line = {
+            "metric": "pair interactions/sec", "value": value, "unit": "Ginter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "n_particles": n, "parallelism": f"i-partition x{world}",
+                       "flops_per_interaction": flops,
+                       "pct_fp64_vector_peak": 100.0 * value * 1e9 * flops / (world * FP64_VECTOR_PEAK_TFLOPS * 1e12)},
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": kernel_avg_ms,
+                         "prepare_ms": float(np.mean(prep_ms))},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(p, pos, m, args.mode)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,14 @@ class Library:
             raise FileNotFoundError(
                 f"{path} not found: build it with `make -C nbody_amd/csrc` "
                 "(or __graft_entry__.build()); there is no fallback path")
+        # torch ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both
+        # open the GPU.  Importing torch first makes the dynamic linker resolve libnbpp's
+        # DT_NEEDED libamdhip64.so.7 to the copy torch already loaded.  Without torch the
+        # system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = self.lib = C.CDLL(path)
         self.path = path
         L.nbpp_init.argtypes = [C.c_int]

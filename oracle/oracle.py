@@ -68,6 +68,15 @@ def _dp(a):
     return a.ctypes.data_as(_DP)
 
 
+def _params(p):
+    """Accept any ctypes struct with the nbpp_params layout (e.g. nbody_amd.ffi.Params)."""
+    if isinstance(p, Params):
+        return p
+    if C.sizeof(p) != C.sizeof(Params):
+        raise TypeError("parameter struct has the wrong size")
+    return Params.from_buffer_copy(bytes(p))
+
+
 def build(quiet=True):
     """Compile the oracle (and _ref where the reference tree exists) with oracle/Makefile."""
     subprocess.run(["make", "-C", HERE], check=True,
@@ -139,6 +148,7 @@ class Oracle:
     def accumulate(self, p, x, y, z, m, acc=None, tgt_begin=0, n_tgt=None,
                    traversal=EXACT, nthreads=0, long_double=False):
         x, y, z, m = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z, m))
+        p = _params(p)
         n = x.size
         if n_tgt is None:
             n_tgt = n - tgt_begin
@@ -159,6 +169,7 @@ class Oracle:
 
     def count_within_cutoff(self, p, x, y, z, tgt_begin=0, n_tgt=None, nthreads=0):
         x, y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z))
+        p = _params(p)
         if n_tgt is None:
             n_tgt = x.size - tgt_begin
         return int(self.lib.orc_count_within_cutoff(C.byref(p), x.size, _dp(x), _dp(y), _dp(z),
