@@ -142,6 +142,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     kernel_ms, prep_ms, accepted = [], [], 0
+    st = {}
     for _ in range(args.steps):
         st = step()
         kernel_ms.append(st["pair_kernel_ms"])
@@ -184,7 +185,9 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": None, "kernel_ms": kernel_avg_ms,
-                         "prepare_ms": float(np.mean(prep_ms))},
+                         "prepare_ms": float(np.mean(prep_ms)),
+                         "subtiles_wrapped_frac": (st.get("subtiles_wrapped", 0) /
+                                                   max(1, st.get("subtiles_total", 0)))},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(p, pos, m, args.mode)

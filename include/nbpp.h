@@ -75,6 +75,9 @@ typedef struct nbpp_stats {
     uint64_t pairs_accepted; /* P3M: ordered pairs with r^2 <= cutoff_sq (needs
                                 NBPP_OPT_TIMING); direct: equal to pairs_evaluated    */
     uint64_t pair_launches;  /* pair-kernel launches in the call                      */
+    uint64_t subtiles_total; /* direct kernels, with NBPP_OPT_TIMING: (wavefront, 64-source
+                                sub-tile) visits ...                                   */
+    uint64_t subtiles_wrapped; /* ... and how many needed the per-pair minimum image   */
     int32_t  kernel_variant; /* which pair kernel ran (NBPP_KERNEL_*)                 */
     int32_t  reserved;
 } nbpp_stats;

@@ -130,6 +130,8 @@ PairConsts make_consts(const nbpp_params* p) {
     k.cutoff_sq = p->cutoff_sq;
     k.inv_width = p->use_pm ? 1.0 / p->trans_width : 0.0;
     k.qscale = static_cast<double>(1 << QBITS) / p->domain_size;
+    k.c15 = 1.5;
+    k.c1875 = 1.875;
     return k;
 }
 
@@ -257,6 +259,11 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
     a.ax = ax; a.ay = ay; a.az = az;
     a.n_tgt_pad = cdiv(n_tgt, 64) * 64;
     a.k = k;
+    if (g.opt_timing) {
+        CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
+        a.tile_counts = g.counter.as<unsigned long long>();
+    }
     if (split > 1) {
         for (Buf& b : g.part) CHK(b.ensure(sizeof(double) * static_cast<size_t>(split) * a.n_tgt_pad));
         a.px = g.part[0].as<double>(); a.py = g.part[1].as<double>(); a.pz = g.part[2].as<double>();
@@ -326,8 +333,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         tx = g.tgt.x.as<double>(); ty = g.tgt.y.as<double>(); tz = g.tgt.z.as<double>();
         tperm = g.tgt.order.as<int>();
     }
-    CHK(g.counter.ensure(sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(g.counter.p, 0, sizeof(unsigned long long), s));
+    CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
     if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[1], s));
 
     P3MArgs a{};
@@ -390,6 +397,10 @@ int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const
             HIPCHK(hipMemcpy(&hits, g.counter.p, sizeof(hits), hipMemcpyDeviceToHost));
             g.stats.pairs_accepted = hits;
         } else {
+            unsigned long long tc[2] = {0, 0};
+            HIPCHK(hipMemcpy(tc, g.counter.p, sizeof(tc), hipMemcpyDeviceToHost));
+            g.stats.subtiles_total = tc[0];
+            g.stats.subtiles_wrapped = tc[1];
             g.stats.pairs_accepted = g.stats.pairs_evaluated;
         }
     }

@@ -35,6 +35,8 @@ struct PairConsts {
     double cutoff_sq;       // (:150)
     double inv_width;       // 1 / CUTOFF_TRANSITION_WIDTH (:151, :333)
     double qscale;          // 2^QBITS / L
+    double c15, c1875;      // 1.5 and 1.875, passed as data so that they live in registers
+                            // (as literals the compiler re-materialises them per pair)
 };
 
 // ---------------------------------------------------------------------------------
@@ -84,23 +86,23 @@ __device__ __forceinline__ double min_image(double d, double L, double half_L) {
 
 // One source acting on one target, direct summation (use_pm == 0).
 //   (dx,dy,dz) minimum-image displacement, gm = G*m_j.          src/particles.cpp:349-359
+// 16 fp64 VALU instructions + one v_rsq_f64 per pair:
+//   q = eps^2 + dz^2 + dy^2 + dx^2 (3 fma) ; y = rsq(q) ; y2 = y*y ; h = 1 - q*y2 ;
+//   w = (gm*y)*y2 ; s = w + w*h*(1.5 + 1.875 h) ; a += s*d (3 fma)        [+ 3 sub for d]
+// v_rsq_f64 has a relative error below 2^-24, so |h| < 2^-23 and the dropped h^3 term of
+// (1-h)^(-3/2) is below 2^-67.
 template <bool SOFT0>
 __device__ __forceinline__ void pair_direct(double dx, double dy, double dz, double gm,
-                                            double eps2, double& ax, double& ay, double& az) {
-    const double q = __builtin_fma(dx, dx, __builtin_fma(dy, dy, __builtin_fma(dz, dz, eps2)));
-    double s;
-    if constexpr (SOFT0) {
-        s = gm * inv_cube_root2_guarded(q);
-    } else {
-        // fold gm into the cube: (gm*y)*y^2 keeps the op count of the plain cube
-        const float yf = __builtin_amdgcn_rsqf(static_cast<float>(q));
-        const double y = static_cast<double>(yf);
-        const double y2 = y * y;
-        const double h = __builtin_fma(-q, y2, 1.0);
-        const double y3 = (gm * y) * y2;
-        const double c = h * __builtin_fma(1.875, h, 1.5);
-        s = __builtin_fma(y3, c, y3);
-    }
+                                            const PairConsts& k, double& ax, double& ay,
+                                            double& az) {
+    const double q = __builtin_fma(dx, dx, __builtin_fma(dy, dy, __builtin_fma(dz, dz, k.eps2)));
+    const double y = __builtin_amdgcn_rsq(q);
+    const double y2 = y * y;
+    const double h = __builtin_fma(-q, y2, 1.0);
+    const double w = (gm * y) * y2;
+    const double c = h * __builtin_fma(k.c1875, h, k.c15);
+    double s = __builtin_fma(w, c, w);
+    if constexpr (SOFT0) s = (q > 0.0) ? s : 0.0;  // self pair / coincident particles
     ax = __builtin_fma(s, dx, ax);
     ay = __builtin_fma(s, dy, ay);
     az = __builtin_fma(s, dz, az);
@@ -374,6 +376,52 @@ __global__ void __launch_bounds__(WG) k_source_boxes(int npad, const double* __r
 //   MODE 1  direct summation, per-pair wrap everywhere
 //   MODE 2  P3M pair function over all pairs, per-pair wrap (small n / testing)
 // ---------------------------------------------------------------------------------
+// One sub-tile whose displacements along AXIS straddle +L/2 (sigma = +1: all x_j - x_i in
+// [L/4, L)) or -L/2 (sigma = -1: all in (-L, -L/4]); the other two axes have a uniform image
+// shift.  With d0 = x_j - x_i (the reference's first rounding, src/math_utils.h:11-16 is
+// applied to this value), e = L/2 - sigma*d0 is exact (Sterbenz), and
+//     w = copysign(L/2, e) - e
+// equals sigma * wrap(d0) bit for bit: e >= +0 keeps d0 (including d0 == +-L/2, which the
+// reference leaves unwrapped), e < 0 gives sigma*(d0 - sigma*L).  The force component along
+// AXIS is accumulated in the sigma-flipped frame (accumulator multiplied by sigma before and
+// after, both exact).
+template <int I, int AXIS, bool SOFT0>
+__device__ __forceinline__ void straddle_tile(const double4* __restrict__ src, const PairConsts& k,
+                                              double sigma, const double (&shift)[3],
+                                              const double (&xi)[I], const double (&yi)[I],
+                                              const double (&zi)[I], double (&ax)[I],
+                                              double (&ay)[I], double (&az)[I]) {
+    double xs[I], ys[I], zs[I];
+    const double nsig = -sigma;
+    const double half = k.half_L;
+#pragma unroll
+    for (int u = 0; u < I; ++u) {
+        xs[u] = (AXIS == 0) ? xi[u] : xi[u] + shift[0];
+        ys[u] = (AXIS == 1) ? yi[u] : yi[u] + shift[1];
+        zs[u] = (AXIS == 2) ? zi[u] : zi[u] + shift[2];
+        if (AXIS == 0) ax[u] *= sigma;
+        if (AXIS == 1) ay[u] *= sigma;
+        if (AXIS == 2) az[u] *= sigma;
+    }
+#pragma unroll 2
+    for (int j = 0; j < SUB; ++j) {
+        const double4 pj = src[j];
+#pragma unroll
+        for (int u = 0; u < I; ++u) {
+            double d[3] = {pj.x - xs[u], pj.y - ys[u], pj.z - zs[u]};
+            const double e = __builtin_fma(nsig, d[AXIS], half);
+            d[AXIS] = __builtin_copysign(half, e) - e;
+            pair_direct<SOFT0>(d[0], d[1], d[2], pj.w, k, ax[u], ay[u], az[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < I; ++u) {
+        if (AXIS == 0) ax[u] *= sigma;
+        if (AXIS == 1) ay[u] *= sigma;
+        if (AXIS == 2) az[u] *= sigma;
+    }
+}
+
 struct PairArgs {
     const double* sx; const double* sy; const double* sz; const double* sgm;
     const int* sbox;      // [n_src_pad / SUB][8]
@@ -385,11 +433,13 @@ struct PairArgs {
     double* ax; double* ay; double* az;       // output (accumulated into) when gridDim.y == 1
     double* px; double* py; double* pz;       // partial sums [gridDim.y][n_tgt_pad] otherwise
     int n_tgt_pad;
+    unsigned long long* tile_counts;   // optional: [0] (wavefront, sub-tile) visits, [1] of them
+                                       // processed with the per-pair wrap
     PairConsts k;
 };
 
 template <int I, int MODE, bool SOFT0>
-__global__ void __launch_bounds__(WG) k_pairs(const PairArgs a) {
+__global__ void __launch_bounds__(WG, 4) k_pairs(const PairArgs a) {  // 4 waves/SIMD: <= 128 VGPRs
     __shared__ __attribute__((aligned(32))) double4 tile[2][TJ];
     __shared__ int boxes[2][(TJ / SUB) * 8];
 
@@ -426,6 +476,8 @@ __global__ void __launch_bounds__(WG) k_pairs(const PairArgs a) {
     int tile_end = tile_begin + a.tiles_per_split;
     tile_end = tile_end < n_tiles ? tile_end : n_tiles;
 
+    unsigned n_visits = 0, n_slow = 0;
+
     // prologue: stage the first tile
     double4 stage;
     int stage_box = 0;
@@ -449,10 +501,12 @@ __global__ void __launch_bounds__(WG) k_pairs(const PairArgs a) {
 #pragma unroll 1
         for (int s = 0; s < TJ / SUB; ++s) {
             const double4* __restrict__ src = &tile[buf][s * SUB];
-            bool fast = false;
+            // Per axis: 0 = every pair has the same image (shift known), 1 = displacements
+            // straddle +L/2 or -L/2 (sigma says which), 2 = anything else.
+            int n_straddle = 0, n_generic = 0, straddle_axis = 0;
             double shift[3] = {0.0, 0.0, 0.0};
+            double sigma = 1.0;
             if constexpr (MODE == 0) {
-                fast = true;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int jlo = __builtin_amdgcn_readfirstlane(boxes[buf][s * 8 + 2 * c]);
@@ -465,12 +519,19 @@ __global__ void __launch_bounds__(WG) k_pairs(const PairArgs a) {
                         shift[c] = k.L;            // every pair: d - L == x_j - (x_i + L)
                     } else if (dhi <= -(QHALF + 1)) {
                         shift[c] = -k.L;           // every pair: d + L == x_j - (x_i - L)
+                    } else if (dlo >= QHALF / 2) {
+                        ++n_straddle; straddle_axis = c; sigma = 1.0;    // all d in [L/4, L)
+                    } else if (dhi <= -(QHALF / 2)) {
+                        ++n_straddle; straddle_axis = c; sigma = -1.0;   // all d in (-L, -L/4]
                     } else {
-                        fast = false;
+                        ++n_generic;
                     }
                 }
+            } else {
+                n_generic = 3;
             }
-            if (fast) {
+            ++n_visits;
+            if (n_generic == 0 && n_straddle == 0) {
                 double xs[I], ys[I], zs[I];
 #pragma unroll
                 for (int u = 0; u < I; ++u) {
@@ -481,10 +542,19 @@ __global__ void __launch_bounds__(WG) k_pairs(const PairArgs a) {
                     const double4 pj = src[j];
 #pragma unroll
                     for (int u = 0; u < I; ++u)
-                        pair_direct<SOFT0>(pj.x - xs[u], pj.y - ys[u], pj.z - zs[u], pj.w, k.eps2,
+                        pair_direct<SOFT0>(pj.x - xs[u], pj.y - ys[u], pj.z - zs[u], pj.w, k,
                                            ax[u], ay[u], az[u]);
                 }
+            } else if (n_generic == 0 && n_straddle == 1) {
+                ++n_slow;
+                if (straddle_axis == 0)
+                    straddle_tile<I, 0, SOFT0>(src, k, sigma, shift, xi, yi, zi, ax, ay, az);
+                else if (straddle_axis == 1)
+                    straddle_tile<I, 1, SOFT0>(src, k, sigma, shift, xi, yi, zi, ax, ay, az);
+                else
+                    straddle_tile<I, 2, SOFT0>(src, k, sigma, shift, xi, yi, zi, ax, ay, az);
             } else {
+                ++n_slow;
 #pragma unroll 2
                 for (int j = 0; j < SUB; ++j) {
                     const double4 pj = src[j];
@@ -496,11 +566,16 @@ __global__ void __launch_bounds__(WG) k_pairs(const PairArgs a) {
                         if constexpr (MODE == 2)
                             pair_p3m(dx, dy, dz, pj.w, k, ax[u], ay[u], az[u]);
                         else
-                            pair_direct<SOFT0>(dx, dy, dz, pj.w, k.eps2, ax[u], ay[u], az[u]);
+                            pair_direct<SOFT0>(dx, dy, dz, pj.w, k, ax[u], ay[u], az[u]);
                     }
                 }
             }
         }
+    }
+
+    if (a.tile_counts && lane == 0) {
+        atomicAdd(&a.tile_counts[0], static_cast<unsigned long long>(n_visits));
+        atomicAdd(&a.tile_counts[1], static_cast<unsigned long long>(n_slow));
     }
 
     // epilogue: scatter to the caller's order, or store this slice's partial sums

@@ -38,7 +38,8 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("pair_kernel_ms", "prepare_ms", "total_ms",
                                           "h2d_ms", "d2h_ms")] + [
         (k, C.c_uint64) for k in ("n_sources", "n_targets", "pairs_evaluated",
-                                  "pairs_accepted", "pair_launches")] + [
+                                  "pairs_accepted", "pair_launches", "subtiles_total",
+                                  "subtiles_wrapped")] + [
         ("kernel_variant", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):

@@ -28,7 +28,7 @@ def test_header_and_library_agree():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(ffi.Params) == 9 * 8 + 2 * 4
-    assert ctypes.sizeof(ffi.Stats) == 5 * 8 + 5 * 8 + 2 * 4
+    assert ctypes.sizeof(ffi.Stats) == 5 * 8 + 7 * 8 + 2 * 4
     from oracle.oracle import Params as OrcParams
     assert [f[0] for f in OrcParams._fields_] == [f[0] for f in ffi.Params._fields_]
 
