@@ -95,40 +95,22 @@ def main():
     pos = datasets.jittered_lattice(n_side)           # same seeded set on every rank
     m = np.full(n, config.DM_PARTICLE_MASS)
 
-    # i-partition: contiguous, near-equal slices of the particle index range
-    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
-    begin = sum(counts[:rank])
-    mine = counts[rank]
-    maxc = max(counts)
-
-    # device-resident state: each rank owns its slice of x, y, z; masses are gathered once
-    own = [torch.zeros(maxc, dtype=torch.float64, device=dev) for _ in range(3)]
-    for c in range(3):
-        own[c][:mine] = torch.from_numpy(pos[c][begin:begin + mine]).to(dev)
-    mass = torch.from_numpy(m).to(dev)
-    full = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3)]
-    gathered = [torch.empty(maxc * world, dtype=torch.float64, device=dev) for _ in range(3)]
+    # i-partition (nbody_amd/distributed.py): each rank owns a contiguous slice of x, y, z,
+    # resident on its GPU; masses are all-gathered once, positions every step
+    from nbody_amd.distributed import SlicedParticles, force_evaluation
+    parts = SlicedParticles(n, rank, world, dev)
+    parts.set_own_from_global(*[torch.from_numpy(c).to(dev) for c in pos])
+    begin, mine, counts = parts.begin, parts.count, parts.counts
+    mass = parts.gather_scalar_field(torch.from_numpy(m[begin:begin + mine]).to(dev)).contiguous()
     acc = [torch.zeros(mine, dtype=torch.float64, device=dev) for _ in range(3)]
     stream = torch.cuda.current_stream().cuda_stream
 
+    def compute(x, y, z, mm, ax, ay, az, tgt_begin, n_tgt):
+        lib.accumulate_device(p, x, y, z, mm, ax, ay, az, tgt_begin=tgt_begin, n_tgt=n_tgt,
+                              stream=stream)
+
     def step():
-        if world > 1:
-            for c in range(3):
-                dist.all_gather_into_tensor(gathered[c], own[c])
-                if n % world == 0:
-                    full[c] = gathered[c]
-                else:
-                    off = 0
-                    for r in range(world):
-                        full[c][off:off + counts[r]] = gathered[c][r * maxc:r * maxc + counts[r]]
-                        off += counts[r]
-        else:
-            for c in range(3):
-                full[c] = own[c]
-        for a in acc:
-            a.zero_()
-        lib.accumulate_device(p, full[0], full[1], full[2], mass, *acc, tgt_begin=begin,
-                              n_tgt=mine, stream=stream)
+        force_evaluation(parts, mass, acc, compute)
         return lib.stats()
 
     def fence():
@@ -174,6 +156,14 @@ def main():
         # dominant kernel on rank 0's share: algorithmic flops of one launch / its duration
         my_pairs = pairs_per_step * (counts[0] / n)
         achieved = my_pairs * flops / (kernel_avg_ms * 1e-3) / 1e12
+        # HBM bytes per launch come from the committed rocprofv3 counter passes of this same
+        # command (FETCH_SIZE doubled as the gfx950 correction requires, plus WRITE_SIZE)
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "latest_direct128.json" if not use_pm else "latest_p3m.json")
+        if os.path.exists(prof) and world == 1 and n_side == (128 if not use_pm else 256):
+            d = json.load(open(prof)).get("derived", {})
+            if "hbm_fetch_bytes_x2" in d and "hbm_write_bytes" in d:
+                traffic = d["hbm_fetch_bytes_x2"] + d["hbm_write_bytes"]
         line = {
             "metric": "pair interactions/sec", "value": value, "unit": "Ginter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,7 +174,8 @@ def main():
                        "pct_fp64_vector_peak": 100.0 * value * 1e9 * flops / (world * FP64_VECTOR_PEAK_TFLOPS * 1e12)},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": kernel_avg_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC)",
+                         "algorithmic_bytes": 56.0 * n, "kernel_ms": kernel_avg_ms,
                          "prepare_ms": float(np.mean(prep_ms)),
                          "subtiles_wrapped_frac": (st.get("subtiles_wrapped", 0) /
                                                    max(1, st.get("subtiles_total", 0)))},

@@ -1,0 +1,230 @@
+// host_tests.cpp - driver and self-tests for the C++ host side (Config / ParticleSystem / KDK)
+// over libnbpp.  The GPU cases restate the reference's own unit tests for this path
+// (tests/test_gravity.cpp:98-155) against the mirrored interface.
+//
+//   nbody_host_tests config <file.ini>     print every Config field (hex floats), no GPU needed
+//   nbody_host_tests gpu-tests             known-answer tests on GPU 0, exit code = failures
+//   nbody_host_tests kdk <in.bin> <out.bin> <steps> <dt> <ini>
+//                                          PP-only KDK steps on particles read from in.bin
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "config.hpp"
+#include "integrator.hpp"
+#include "particles.hpp"
+
+using namespace nbh;
+
+static int g_failures = 0;
+#define REQUIRE(cond)                                                         \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);       \
+            ++g_failures;                                                     \
+        }                                                                     \
+    } while (0)
+
+static bool approx(double got, double want, double rel = 1e-12, double margin = 0.0) {
+    return std::fabs(got - want) <= std::max(margin, rel * std::fabs(want));
+}
+
+static void print_config(const Config& c) {
+#define D(name) std::printf(#name "=%a\n", static_cast<double>(c.name))
+#define I(name) std::printf(#name "=%d\n", static_cast<int>(c.name))
+    D(DOMAIN_SIZE); I(MESH_SIZE); D(BOX_SIZE_MPC); D(OMEGA_BARYON); D(OMEGA_M); D(OMEGA_LAMBDA);
+    D(HUBBLE_PARAM); I(EXPANDING_UNIVERSE); I(N_PER_SIDE); I(STANDING_PARTICLES); D(START_A);
+    D(SIGMA_8); D(SPECTRAL_INDEX); D(INITIAL_GAS_TEMPERATURE_K); I(SEED); I(USE_HYDRO); D(GAMMA);
+    I(USE_PM); I(USE_PP); D(CUTOFF_RADIUS_CELLS); D(CUTOFF_TRANSITION_WIDTH_FACTOR); D(DT_FACTOR);
+    D(MAX_SCALE_FACTOR); D(CFL_SAFETY_FACTOR); D(GRAVITY_DT_FACTOR); I(USE_ADAPTIVE_DT);
+    I(MAX_CYCLES); D(SAVE_HDF5_EVERY_DELTA_A); I(DEBUG_INFO_EVERY_CYCLES);
+    I(ENABLE_ENERGY_DIAGNOSTICS); D(G); D(CELL_SIZE); D(CELL_VOLUME); D(OMEGA_DM);
+    D(CUTOFF_RADIUS); D(CUTOFF_RADIUS_SQUARED); D(CUTOFF_TRANSITION_WIDTH); D(R_SWITCH_START);
+    D(R_SWITCH_START_SQ); I(NUM_DM_PARTICLES); D(DM_PARTICLE_MASS); D(GAS_TOTAL_MASS);
+    D(SOFTENING_SQUARED); D(FIXED_DT);
+#undef D
+#undef I
+}
+
+// tests/test_gravity.cpp:98-113: the shared two-body set-up.
+static Config two_body_config() {
+    Config config;
+    config.MESH_SIZE = 4;
+    config.CELL_SIZE = 2.0;
+    config.DOMAIN_SIZE = 8.0;
+    config.NUM_DM_PARTICLES = 2;
+    config.G = 1.0;
+    config.SOFTENING_SQUARED = 0.0;
+    return config;
+}
+
+static void test_pure_newtonian() {  // tests/test_gravity.cpp:115-134
+    Config config = two_body_config();
+    ParticleSystem sys(config);
+    sys.add_particle(2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 1.0);
+    sys.add_particle(5.0, 2.0, 2.0, 0.0, 0.0, 0.0, 1.0);
+    config.USE_PM = false;
+    config.CUTOFF_RADIUS_SQUARED = (config.DOMAIN_SIZE / 2.0) * (config.DOMAIN_SIZE / 2.0);
+    sys.bin_and_assign_mass(config);
+    sys.compute_pp_forces(config);
+    const double expected_f = 1.0 / 9.0;
+    REQUIRE(approx(sys.acc_x[0], expected_f));
+    REQUIRE(sys.acc_y[0] == 0.0);
+    REQUIRE(sys.acc_z[0] == 0.0);
+    REQUIRE(approx(sys.acc_x[1], -expected_f));
+}
+
+static void test_p3m_cutoff() {  // tests/test_gravity.cpp:136-154
+    Config config = two_body_config();
+    ParticleSystem sys(config);
+    sys.add_particle(2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 1.0);
+    sys.add_particle(5.0, 2.0, 2.0, 0.0, 0.0, 0.0, 1.0);
+    config.USE_PM = true;
+    config.CUTOFF_RADIUS = 2.0;
+    config.CUTOFF_RADIUS_SQUARED = 4.0;
+    config.R_SWITCH_START = 1.0;
+    config.R_SWITCH_START_SQ = 1.0;
+    config.CUTOFF_TRANSITION_WIDTH = 1.0;
+    sys.bin_and_assign_mass(config);
+    std::fill(sys.acc_x.begin(), sys.acc_x.end(), 0.0);
+    sys.compute_pp_forces(config);
+    REQUIRE(sys.acc_x[0] == 0.0);
+    REQUIRE(sys.acc_x[1] == 0.0);
+}
+
+static void test_wrap_through_forces() {  // tests/test_math.cpp:14-37 seen through the force
+    Config config;
+    config.DOMAIN_SIZE = 64.0;
+    config.MESH_SIZE = 8;
+    config.N_PER_SIDE = 2;
+    config.USE_PM = false;
+    config.compute_derived_data();
+    config.G = 1.0;
+    config.SOFTENING_SQUARED = 0.0;
+    ParticleSystem sys(config);
+    sys.add_particle(1.0, 5.0, 5.0, 0, 0, 0, 1.0);   // A at x = 1
+    sys.add_particle(63.0, 5.0, 5.0, 0, 0, 0, 1.0);  // B at x = 63: shortest path is -2
+    sys.compute_pp_forces(config);
+    REQUIRE(approx(sys.acc_x[0], -0.25));
+    REQUIRE(approx(sys.acc_x[1], +0.25));
+}
+
+static void test_accumulate_and_contract() {
+    Config config;
+    config.MESH_SIZE = 8;
+    config.N_PER_SIDE = 6;
+    config.USE_PM = false;
+    config.compute_derived_data();
+    ParticleSystem sys(config);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) / 16777216.0; };
+    for (int i = 0; i < config.NUM_DM_PARTICLES; ++i)
+        sys.add_particle(rnd(), rnd(), rnd(), 0, 0, 0, config.DM_PARTICLE_MASS);
+    sys.compute_pp_forces(config);
+    std::vector<double> once = sys.acc_x;
+    sys.compute_pp_forces(config);  // acc += : second call doubles
+    for (std::size_t i = 0; i < sys.num_particles; ++i) REQUIRE(approx(sys.acc_x[i], 2.0 * once[i], 1e-14));
+    compute_pp_accelerations(sys, config);  // zero-fills first
+    double mx = 1e-9;
+    for (std::size_t i = 0; i < sys.num_particles; ++i) {
+        REQUIRE(approx(sys.acc_x[i], once[i], 1e-14));
+        mx = std::max(mx, sys.acc_x[i] * sys.acc_x[i] + sys.acc_y[i] * sys.acc_y[i] + sys.acc_z[i] * sys.acc_z[i]);
+    }
+    REQUIRE(sys.max_accel_sq == mx);
+    REQUIRE(sys.get_gravity_timestep(config) ==
+            std::sqrt(config.SOFTENING_SQUARED) / std::sqrt(mx) * config.GRAVITY_DT_FACTOR);
+    config.STANDING_PARTICLES = true;  // src/integrator.cpp:263-269
+    compute_pp_accelerations(sys, config);
+    REQUIRE(sys.max_accel_sq == 1e-9);
+    for (std::size_t i = 0; i < sys.num_particles; ++i) REQUIRE(sys.acc_x[i] == 0.0);
+    config.STANDING_PARTICLES = false;
+    config.USE_PP = false;             // src/integrator.cpp:254
+    compute_pp_accelerations(sys, config);
+    REQUIRE(sys.max_accel_sq == 1e-9);
+    // total momentum change of a KDK step is zero (pairwise antisymmetry)
+    config.USE_PP = true;
+    config.EXPANDING_UNIVERSE = false;
+    Cosmology cosmo;
+    compute_pp_accelerations(sys, config);
+    KDK_step(sys, cosmo, config.FIXED_DT, config);
+    double px = 0, scale = 0;
+    for (std::size_t i = 0; i < sys.num_particles; ++i) {
+        px += sys.mass[i] * sys.vel_x[i];
+        scale += sys.mass[i] * std::fabs(sys.vel_x[i]);
+        REQUIRE(sys.pos_x[i] >= 0.0 && sys.pos_x[i] <= config.DOMAIN_SIZE);
+    }
+    REQUIRE(std::fabs(px) < 1e-10 * scale);
+    ParticleSystem empty(config);
+    empty.compute_pp_forces(config);  // n == 0: no-op
+    REQUIRE(std::isinf(empty.get_gravity_timestep(config)));
+}
+
+static int run_kdk(const char* in_path, const char* out_path, int steps, double dt, const char* ini) {
+    Config config;
+    config.load(ini);
+    FILE* f = std::fopen(in_path, "rb");
+    if (!f) throw std::runtime_error("cannot open input");
+    long long n = 0;
+    if (std::fread(&n, sizeof(n), 1, f) != 1) throw std::runtime_error("short read");
+    std::vector<double> buf(7 * n);
+    if (std::fread(buf.data(), sizeof(double), buf.size(), f) != buf.size()) throw std::runtime_error("short read");
+    std::fclose(f);
+    ParticleSystem sys(config);
+    for (long long i = 0; i < n; ++i)
+        sys.add_particle(buf[i], buf[n + i], buf[2 * n + i], buf[3 * n + i], buf[4 * n + i],
+                         buf[5 * n + i], buf[6 * n + i]);
+    Cosmology cosmo;
+    update_cosmology(cosmo, config);
+    compute_pp_accelerations(sys, config);  // initial accelerations, as src/ics.cpp:305-346
+    for (int s = 0; s < steps; ++s) KDK_step(sys, cosmo, dt, config);
+    f = std::fopen(out_path, "wb");
+    if (!f) throw std::runtime_error("cannot open output");
+    std::fwrite(&n, sizeof(n), 1, f);
+    for (auto* v : {&sys.pos_x, &sys.pos_y, &sys.pos_z, &sys.vel_x, &sys.vel_y, &sys.vel_z,
+                    &sys.acc_x, &sys.acc_y, &sys.acc_z})
+        std::fwrite(v->data(), sizeof(double), n, f);
+    const double tail[4] = {sys.max_accel_sq, cosmo.scale_factor, cosmo.hubble_param, cosmo.total_time};
+    std::fwrite(tail, sizeof(double), 4, f);
+    std::fclose(f);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc >= 2 && !std::strcmp(argv[1], "config")) {
+            Config c;
+            if (argc >= 3) c.load(argv[2]);
+            print_config(c);
+            return 0;
+        }
+        if (argc >= 2 && (!std::strcmp(argv[1], "gpu-tests") || !std::strcmp(argv[1], "kdk"))) {
+            if (nbpp_init(0) != NBPP_OK) {
+                std::printf("nbpp_init failed: %s\n", nbpp_last_error());
+                return 2;
+            }
+            int rc = 0;
+            if (!std::strcmp(argv[1], "kdk")) {
+                if (argc < 7) throw std::runtime_error("kdk needs <in> <out> <steps> <dt> <ini>");
+                rc = run_kdk(argv[2], argv[3], std::atoi(argv[4]), std::atof(argv[5]), argv[6]);
+            } else {
+                test_pure_newtonian();
+                test_p3m_cutoff();
+                test_wrap_through_forces();
+                test_accumulate_and_contract();
+                std::printf("%s (%d failures)\n", g_failures ? "FAILED" : "ALL PASSED", g_failures);
+                rc = g_failures ? 1 : 0;
+            }
+            nbpp_shutdown();
+            return rc;
+        }
+        std::printf("usage: %s config [ini] | gpu-tests | kdk <in> <out> <steps> <dt> <ini>\n", argv[0]);
+        return 64;
+    } catch (const std::exception& e) {
+        std::printf("error: %s\n", e.what());
+        return 3;
+    }
+}

@@ -1,0 +1,80 @@
+"""The multi-GPU i-partition, rehearsed with two gloo ranks on CPU tensors.  The arithmetic is
+injected: here the CPU oracle stands in for the GPU kernel, so what is tested is the partition,
+the padded all-gather and the slice bookkeeping that bench.py uses unchanged on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, use_pm, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datasets
+    from nbody_amd import Config
+    from nbody_amd.distributed import SlicedParticles, force_evaluation
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    pos = datasets.clustered(n)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=8, N_PER_SIDE=8, USE_PM=use_pm).pp_params()
+    parts = SlicedParticles(n, rank, world, torch.device("cpu"))
+    parts.set_own_from_global(*[torch.from_numpy(c) for c in pos])
+    mass = parts.gather_scalar_field(torch.from_numpy(m[parts.begin:parts.begin + parts.count]))
+    acc = [torch.full((parts.count,), 7.0, dtype=torch.float64) for _ in range(3)]
+
+    def compute(x, y, z, mm, ax, ay, az, tgt_begin, n_tgt):
+        got = orc.accumulate(p, x.numpy(), y.numpy(), z.numpy(), mm.numpy(), tgt_begin=tgt_begin,
+                             n_tgt=n_tgt, nthreads=2)
+        for dst, src in zip((ax, ay, az), got):
+            dst += torch.from_numpy(src)
+
+    for _ in range(2):  # twice: buffers are reused between evaluations
+        force_evaluation(parts, mass, acc, compute)
+    assert torch.equal(mass, torch.from_numpy(m))
+    np.save(os.path.join(out_dir, f"acc_{rank}.npy"), np.stack([a.numpy() for a in acc]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,use_pm", [(1001, False), (1000, True)])
+def test_two_rank_partition_matches_single_process(tmp_path, oracle, n, use_pm):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, use_pm, str(tmp_path)), nprocs=2, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datasets
+    from nbody_amd import Config
+    pos = datasets.clustered(n)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=8, N_PER_SIDE=8, USE_PM=use_pm).pp_params()
+    want = np.stack(oracle.accumulate(p, *pos, m))
+    got = np.concatenate([np.load(tmp_path / f"acc_{r}.npy") for r in range(2)], axis=1)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)  # same oracle, same order per target: bitwise
+
+
+def test_partition_shapes():
+    from nbody_amd.distributed import partition
+    for n, w in ((10, 3), (8, 8), (2097152, 8), (5, 8), (0, 2)):
+        begins, counts = partition(n, w)
+        assert sum(counts) == n and begins[0] == 0
+        assert all(begins[r + 1] == begins[r] + counts[r] for r in range(w - 1))
+        assert max(counts) - min(counts) <= 1
