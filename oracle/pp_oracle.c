@@ -386,3 +386,84 @@ int orc_max_threads(void) {
     return 1;
 #endif
 }
+
+/*
+ * Standard-normal deviates exactly as libstdc++ produces them for
+ *     std::default_random_engine generator(seed);            (= std::minstd_rand0)
+ *     std::normal_distribution<double> distribution(0.0, 1.0);
+ * which is how the reference fills its white-noise field (src/ics.cpp:62-66).  libstdc++'s
+ * algorithm: Marsaglia polar method on generate_canonical<double,53>, which for minstd_rand0
+ * (range 2147483646 < 2^31) consumes two engine outputs per canonical deviate; of each
+ * accepted pair the second coordinate is returned first and the first is saved.
+ */
+static inline uint32_t minstd0_next(uint32_t* s) {
+    *s = (uint32_t)(((uint64_t)(*s) * 16807u) % 2147483647u);
+    return *s;
+}
+
+static inline double minstd0_canonical(uint32_t* s) {
+    const double r = 2147483646.0; /* max - min + 1 */
+    double sum = (double)(minstd0_next(s) - 1u);
+    sum += (double)(minstd0_next(s) - 1u) * r;
+    double ret = sum / (r * r);
+    if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+    return ret;
+}
+
+void orc_libstdcxx_normal_field(uint32_t seed, size_t n, double* out) {
+    uint32_t s = seed % 2147483647u;
+    if (s == 0) s = 1; /* linear_congruential_engine::seed with c == 0 */
+    int have_saved = 0;
+    double saved = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        if (have_saved) {
+            have_saved = 0;
+            out[i] = saved;
+            continue;
+        }
+        double x, y, r2;
+        do {
+            x = 2.0 * minstd0_canonical(&s) - 1.0;
+            y = 2.0 * minstd0_canonical(&s) - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = sqrt(-2 * log(r2) / r2);
+        saved = x * mult;
+        have_saved = 1;
+        out[i] = y * mult;
+    }
+}
+
+/* sigma_8 normalisation integral of src/ics.cpp:38-51: the same loop, the same running k. */
+static double bbks_unnormalized_pk(double k_h, double omega_m, double hubble, double n_s) {
+    const double Gamma = omega_m * hubble;                                /* src/ics.cpp:14 */
+    const double q = k_h / Gamma;                                         /* :17 */
+    const double T_k = log(1.0 + 2.34 * q) / (2.34 * q) *
+                       pow(1.0 + 3.89 * q + pow(16.1 * q, 2) + pow(5.46 * q, 3) + pow(6.71 * q, 4),
+                           -0.25);                                        /* :20-23 */
+    return pow(k_h, n_s) * T_k * T_k;                                     /* :26 */
+}
+
+double orc_bbks_pk(double k_h, double omega_m, double hubble, double n_s) {
+    return bbks_unnormalized_pk(k_h, omega_m, hubble, n_s);
+}
+
+double orc_sigma8_amplitude(double sigma_8, double omega_m, double hubble, double n_s) {
+    const double R = 8.0, dk = 0.001;                                     /* :38,:40 */
+    double unnorm_variance = 0.0;
+    for (double k = 0.001; k < 100.0; k += dk) {                          /* :43 */
+        const double pk = bbks_unnormalized_pk(k, omega_m, hubble, n_s);
+        const double kR = k * R;
+        const double w = (kR < 1e-4) ? 1.0 - (kR * kR / 10.0)
+                                     : 3.0 * (sin(kR) - kR * cos(kR)) / (kR * kR * kR); /* :32-33 */
+        unnorm_variance += pk * w * w * k * k * dk;                       /* :46 */
+    }
+    unnorm_variance /= (2.0 * M_PI * M_PI);                               /* :48 */
+    return (sigma_8 * sigma_8) / unnorm_variance;                         /* :51 */
+}
+
+void orc_bbks_pk_array(size_t n, const double* k_h, double omega_m, double hubble, double n_s,
+                       double* out) {
+    for (size_t i = 0; i < n; ++i)
+        out[i] = (k_h[i] > 0.0) ? bbks_unnormalized_pk(k_h[i], omega_m, hubble, n_s) : 0.0;
+}

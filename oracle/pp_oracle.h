@@ -91,6 +91,15 @@ double orc_gravity_timestep(size_t n, double softening_squared, double max_accel
                             double gravity_dt_factor);
 int orc_max_threads(void);
 
+/* Pieces of the reference's Zel'dovich initial conditions (src/ics.cpp:36-165) that need C:
+ * the libstdc++ white-noise stream and the sigma_8 normalisation loop.  The FFT part is in
+ * oracle/zeldovich.py. */
+void orc_libstdcxx_normal_field(uint32_t seed, size_t n, double* out);
+double orc_bbks_pk(double k_h, double omega_m, double hubble, double n_s);
+double orc_sigma8_amplitude(double sigma_8, double omega_m, double hubble, double n_s);
+void orc_bbks_pk_array(size_t n, const double* k_h, double omega_m, double hubble, double n_s,
+                       double* out);
+
 #ifdef __cplusplus
 }
 #endif

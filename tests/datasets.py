@@ -39,3 +39,11 @@ def masses(n, equal=True, total=0.84, seed=3):
     rng = np.random.Generator(np.random.MT19937(seed))
     m = rng.random(n) + 0.5
     return m * (total / m.sum())
+
+
+def zeldovich(n_side, mesh_size=None, seed=42):
+    """Zel'dovich initial conditions exactly as the reference generates them (restated in
+    oracle/zeldovich.py; test infrastructure).  Returns positions [x, y, z]."""
+    from oracle.zeldovich import zeldovich_particles
+    pos, _, _ = zeldovich_particles(n_per_side=n_side, mesh_size=mesh_size or n_side, seed=seed)
+    return pos

@@ -79,6 +79,17 @@ def main():
                       {"dx": -2.0, "expect": -2.0}, {"dx": 32.0, "expect_abs": 32.0}],
         },
     }
+    # Values a build of the reference printed for the shipped simulation.ini (seed 42, 32^3,
+    # mesh 32) during the survey of the reference; transcribed, not regenerated here.
+    kat["default_ini_anchor"] = {
+        "source": "initialize_state (src/ics.cpp:290-349) on /root/reference/simulation.ini",
+        "scale_factor": 0.020000000000000007, "hubble_param": 235.70446027301335,
+        "p0_pos": [0.016061997996275945, 0.012630329609784496, 0.014442457643764284],
+        "p0_vel": [0.10300131937684433, -0.70584992132590851, -0.27872764623469792],
+        "p0_acc_initial_pm_plus_pp": [0.00038592991125482439, -0.0018989432424388109,
+                                      -0.00086020514888652676],
+        "max_accel_sq": 2.5834272123748411e-05,
+    }
     with open(os.path.join(HERE, "reference_kat.json"), "w") as f:
         json.dump(kat, f, indent=1)
 

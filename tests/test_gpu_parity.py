@@ -385,3 +385,38 @@ def test_128cubed_sampled_targets_and_momentum(lib, oracle):
     typical = np.mean(np.sqrt(got[0] ** 2 + got[1] ** 2 + got[2] ** 2)) * m[0] * n
     for c in range(3):
         assert abs(np.sum(m * got[c])) < 1e-9 * typical
+
+
+# --------------------------------------------------------------------------------------
+# Zel'dovich initial conditions (the particle sets the reference actually starts from)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_side", [16, 32])
+@pytest.mark.parametrize("use_pm", [False, True])
+def test_zeldovich_ics(lib, oracle, n_side, use_pm):
+    pos = datasets.zeldovich(n_side)
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm, OMEGA_BARYON=0.048)
+    m = np.full(n_side ** 3, config.DM_PARTICLE_MASS)
+    p = config.pp_params()
+    # P3M: the reference's own CPU-branch traversal (exact at mesh >= 7, <= 1500 neighbours);
+    # PP-only: the exact sum (what the reference's offload branch gives on an odd mesh)
+    want = oracle.accumulate(p, *pos, m, traversal=O.REF_CPU if use_pm else O.EXACT)
+    got = gpu_acc(lib, p, pos, m)
+    assert normalised_error(got, want) < TOL
+
+
+def test_default_ini_total_acceleration_matches_reference_output(lib, oracle):
+    """GPU short-range force + restated mesh force on the shipped simulation.ini against the
+    values a build of the reference printed (tests/golden/reference_kat.json)."""
+    from oracle.pm_mesh import initial_mesh_accelerations
+    from oracle.zeldovich import zeldovich_particles
+    kat = json.load(open(os.path.join(GOLDEN, "reference_kat.json")))["default_ini_anchor"]
+    cfg = json.load(open(os.path.join(GOLDEN, "reference_config.json")))["simulation_ini"]
+    pos, _, _ = zeldovich_particles(oracle=oracle)
+    m = np.full(32768, cfg["dm_particle_mass"])
+    acc = initial_mesh_accelerations(pos, m, 32, 1.0, cfg["G"], cfg["gas_total_mass"])
+    config = Config(OMEGA_BARYON=cfg["omega_baryon"])
+    lib.accumulate(config.pp_params(), *pos, m, *acc)   # acc += PP, as src/ics.cpp:319-322
+    for c in range(3):
+        assert acc[c][0] == pytest.approx(kat["p0_acc_initial_pm_plus_pp"][c], rel=1e-12)
+    assert float(np.max(acc[0] ** 2 + acc[1] ** 2 + acc[2] ** 2)) == \
+        pytest.approx(kat["max_accel_sq"], rel=1e-12)

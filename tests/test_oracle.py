@@ -219,3 +219,27 @@ def test_caller_contract_pieces(oracle):
     assert oracle.max_accel_sq(tiny) == 1e-9
     assert oracle.gravity_timestep(10, 4e-6, 1e-4, 0.2) == np.sqrt(4e-6) / np.sqrt(1e-4) * 0.2
     assert oracle.gravity_timestep(0, 4e-6, 1e-4, 0.2) == np.inf
+
+
+def test_zeldovich_ics_and_total_acceleration_match_reference_output(oracle):
+    """The shipped simulation.ini through the restated pipeline (white noise -> Zel'dovich
+    displacements -> particles -> mesh force + short-range force) against the numbers a build
+    of the reference printed: particle 0's position bit for bit, its total initial acceleration
+    and the global max |a|^2 to 1e-13."""
+    from oracle.zeldovich import zeldovich_particles
+    from oracle.pm_mesh import initial_mesh_accelerations
+    anchor = _golden("reference_kat.json")["default_ini_anchor"]
+    cfg = _golden("reference_config.json")["simulation_ini"]
+    pos, vel, info = zeldovich_particles(oracle=oracle)
+    assert info["scale_factor"] == anchor["scale_factor"]
+    assert info["hubble_param"] == anchor["hubble_param"]
+    for c in range(3):
+        assert pos[c][0] == anchor["p0_pos"][c]
+        assert vel[c][0] == pytest.approx(anchor["p0_vel"][c], rel=1e-13)
+    m = np.full(pos[0].size, cfg["dm_particle_mass"])
+    acc = initial_mesh_accelerations(pos, m, 32, 1.0, cfg["G"], cfg["gas_total_mass"])
+    p = oracle.params_from_config(1, omega_baryon=cfg["omega_baryon"])
+    oracle.accumulate(p, *pos, m, acc=acc, traversal=O.REF_CPU)
+    for c in range(3):
+        assert acc[c][0] == pytest.approx(anchor["p0_acc_initial_pm_plus_pp"][c], rel=1e-13)
+    assert oracle.max_accel_sq(acc) == pytest.approx(anchor["max_accel_sq"], rel=1e-13)
