@@ -302,55 +302,78 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     const PairConsts k = make_consts(p);
     int R = 0, nside = 0;
     if (!p3m_search_grid(p, &R, &nside)) return fail(NBPP_ERR_ARG, "box too small for the cell search");
-    BinGrid grid;
+    if (n_src > (1 << GHOST_SHIFT))
+        return fail(NBPP_ERR_RANGE, "the P3M cell kernel indexes at most 2^26 sources (got %d)", n_src);
+    GhostGrid grid;
     grid.nside = nside;
+    grid.R = R;
+    grid.np = nside + 2 * R;
     grid.scale = nside / p->domain_size;
-    grid.morton = 0;
+    grid.L = p->domain_size;
+    const long long ncell = 1LL * grid.np * grid.np * grid.np;
+    if (ncell + 1 > 0x7fffffffLL) return fail(NBPP_ERR_RANGE, "search grid too large");
 
+    // 1. positions into [0, L), histogram over real + ghost cells, offsets
     for (Buf& b : g.canon) CHK(b.ensure(sizeof(double) * n_src));
     double *cx = g.canon[0].as<double>(), *cy = g.canon[1].as<double>(), *cz = g.canon[2].as<double>();
+    CHK(g.count.ensure(sizeof(int) * (ncell + 1)));
+    CHK(g.src.start.ensure(sizeof(int) * (ncell + 1)));
+    int* count = g.count.as<int>();
+    int* start = g.src.start.as<int>();
     hipLaunchKernelGGL(k_canonical_positions, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z,
                        p->domain_size, cx, cy, cz);
-    CHK(sort_by_cell(n_src, cx, cy, cz, grid, g.src, s));
-    for (Buf* b : {&g.src.x, &g.src.y, &g.src.z, &g.src.gm}) CHK(b->ensure(sizeof(double) * n_src));
-    hipLaunchKernelGGL(k_gather_sources, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, n_src,
-                       g.src.order.as<int>(), cx, cy, cz, m, p->G, g.src.x.as<double>(),
-                       g.src.y.as<double>(), g.src.z.as<double>(), g.src.gm.as<double>());
-    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
+    hipLaunchKernelGGL(k_ghost_count, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid, count);
+    CHK(exclusive_scan(static_cast<int>(ncell + 1), count, start, s));
+    int n_entries = 0;  // the one host read-back of the call: real + ghost entries
+    HIPCHK(hipMemcpyAsync(&n_entries, start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_entries < n_src) return fail(NBPP_ERR_HIP, "binning lost particles (%d < %d)", n_entries, n_src);
 
-    const double *tx, *ty, *tz;
-    const int* tperm;
-    if (tgt_begin == 0 && n_tgt == n_src) {
-        tx = g.src.x.as<double>(); ty = g.src.y.as<double>(); tz = g.src.z.as<double>();
-        tperm = g.src.order.as<int>();
-    } else {
-        CHK(sort_by_cell(n_tgt, cx + tgt_begin, cy + tgt_begin, cz + tgt_begin, grid, g.tgt, s));
-        for (Buf* b : {&g.tgt.x, &g.tgt.y, &g.tgt.z}) CHK(b->ensure(sizeof(double) * n_tgt));
-        hipLaunchKernelGGL(k_gather_targets, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, n_tgt, n_tgt,
-                           g.tgt.order.as<int>(), cx + tgt_begin, cy + tgt_begin, cz + tgt_begin,
-                           g.tgt.x.as<double>(), g.tgt.y.as<double>(), g.tgt.z.as<double>());
-        HIPCHK(hipGetLastError());
-        tx = g.tgt.x.as<double>(); ty = g.tgt.y.as<double>(); tz = g.tgt.z.as<double>();
-        tperm = g.tgt.order.as<int>();
-    }
+    // 2. scatter, canonical order inside each cell, records
+    CHK(g.src.order.ensure(sizeof(int) * n_entries));
+    CHK(g.src.x.ensure(sizeof(double4) * n_entries));  // AoS records live in the x buffer
+    int* entries = g.src.order.as<int>();
+    double4* rec = g.src.x.as<double4>();
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
+    hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
+                       start, count, entries);
+    hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s, static_cast<int>(ncell),
+                       start, entries);
+    hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries,
+                       cx, cy, cz, m, p->G, p->domain_size, rec);
+
+    // 3. compact list of targets in sorted order
+    CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));
+    CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
+    CHK(g.tgt.order.ensure(sizeof(int) * n_tgt));
+    int* flag = g.src.cell.as<int>();
+    int* slot = g.src.rank.as<int>();
+    int* tlist = g.tgt.order.as<int>();
+    hipLaunchKernelGGL(k_target_flags, dim3(cdiv(n_entries + 1, WG)), dim3(WG), 0, s, n_entries, entries,
+                       tgt_begin, n_tgt, flag);
+    CHK(exclusive_scan(n_entries + 1, flag, slot, s));
+    hipLaunchKernelGGL(k_target_scatter, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, flag, slot,
+                       tlist);
+    HIPCHK(hipGetLastError());
     CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
     if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[1], s));
 
+    // 4. pairs
     P3MArgs a{};
-    a.sx = g.src.x.as<double>(); a.sy = g.src.y.as<double>(); a.sz = g.src.z.as<double>();
-    a.sgm = g.src.gm.as<double>(); a.cell_start = g.src.start.as<int>();
-    a.nside = nside; a.R = R; a.cell_scale = grid.scale;
-    a.tx = tx; a.ty = ty; a.tz = tz; a.tperm = tperm; a.n_tgt = n_tgt;
+    a.rec = rec; a.entries = entries; a.cell_start = start; a.tlist = tlist;
+    a.n_entries = n_entries; a.n_tgt = n_tgt; a.tgt_begin = tgt_begin; a.g = grid;
     a.ax = ax; a.ay = ay; a.az = az;
     a.accepted = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
     a.k = k;
-    hipLaunchKernelGGL(k_p3m_cells, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, a);
+    if (p->soft_sq == 0.0)
+        hipLaunchKernelGGL(k_p3m_cells<true>, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_p3m_cells<false>, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, a);
     HIPCHK(hipGetLastError());
-    const long long span = 2LL * R + 1;
     g.stats.pairs_evaluated = 0;  // candidates depend on the data; see pairs_accepted
     g.stats.pair_launches = 1;
-    (void)span;
     return NBPP_OK;
 }
 

@@ -597,90 +597,220 @@ __global__ void __launch_bounds__(WG, 4) k_pairs(const PairArgs a) {  // 4 waves
 // ---------------------------------------------------------------------------------
 // P3M short range over a cell list.
 //
-// Sources are counting-sorted by the cells of a search grid (x fastest, as the reference's
-// cell id, src/particles.cpp:94) whose cell size c satisfies R*c >= cutoff radius, so all
-// partners of a target lie in the (2R+1)^3 cells around its own cell
-// (the reference's sweep: src/particles.cpp:187-197 / :287-297 with
-// R = ceil(CUTOFF_RADIUS / CELL_SIZE), :134-137).  Because x is the fastest cell index,
-// the 2R+1 cells of one (dy, dz) row are one contiguous run of the sorted arrays.
+// Search grid: `nside` cells per axis with R*cell >= cutoff radius, so all partners of a
+// target lie in the (2R+1)^3 cells around its own cell (the reference's sweep:
+// src/particles.cpp:187-197 / :287-297 with R = ceil(CUTOFF_RADIUS / CELL_SIZE), :134-137).
+// The grid is stored with R ghost layers on every side: a particle within R cells of a face
+// is entered a second (up to eighth) time in the ghost cell beyond the opposite face, with its
+// coordinate already shifted by +-L.  The pair kernel therefore never wraps anything: the image
+// implied by the ghost cell is the minimum image because nside >= 2R+3 keeps (R+1)*cell < L/2.
+// Cell ids are z-fastest, id = (ix*np + iy)*np + iz, so the 2R+1 cells of one (dx,dy) row are
+// one contiguous run of the sorted record array.  (The reference numbers its cells x-fastest,
+// src/particles.cpp:94; z-fastest matches the order in which its initial conditions enumerate
+// particles, src/ics.cpp:174-187, which keeps the binning passes close to sequential.)
 //
-// One lane per target; lanes of a wavefront are consecutive sorted targets, i.e. spatial
-// neighbours walking nearly the same runs (their loads share cache lines).
-//
-// Minimum image: the grid has at least 2R+3 cells per side, so (R+1)*c < L/2 and the image
-// implied by the cell wrap is the reference's minimum image.  The shift is applied to the
-// lane's target coordinate once per run, not per pair.
+// Entries of the sorted array are 32-bit: original index (26 bits) | image code (2 bits per
+// axis: 0 none, 1 = +L, 2 = -L) << 26.
 // ---------------------------------------------------------------------------------
+constexpr int GHOST_SHIFT = 26;
+constexpr unsigned GHOST_INDEX_MASK = (1u << GHOST_SHIFT) - 1u;
+
+struct GhostGrid {
+    double scale;   // nside / L
+    double L;
+    int nside;      // real cells per axis
+    int R;          // ghost layers = search radius in cells
+    int np;         // nside + 2R
+};
+
+// Calls f(padded_cell_id, code) for every image of a particle at canonical (x, y, z).
+template <class F>
+__device__ __forceinline__ void for_each_image(double x, double y, double z, const GhostGrid g, F f) {
+    const int c[3] = {bin_coord(x, g.scale, g.nside), bin_coord(y, g.scale, g.nside),
+                      bin_coord(z, g.scale, g.nside)};
+    int idx[3][2], code[3][2], cnt[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        idx[a][0] = c[a] + g.R; code[a][0] = 0; cnt[a] = 1;
+        if (c[a] < g.R) { idx[a][1] = c[a] + g.nside + g.R; code[a][1] = 1; cnt[a] = 2; }
+        else if (c[a] >= g.nside - g.R) { idx[a][1] = c[a] - g.nside + g.R; code[a][1] = 2; cnt[a] = 2; }
+    }
+    for (int iz = 0; iz < cnt[2]; ++iz)
+        for (int iy = 0; iy < cnt[1]; ++iy)
+            for (int ix = 0; ix < cnt[0]; ++ix)
+                f((idx[0][ix] * g.np + idx[1][iy]) * g.np + idx[2][iz],
+                  static_cast<unsigned>(code[0][ix] | (code[1][iy] << 2) | (code[2][iz] << 4)));
+}
+
+__global__ void k_ghost_count(int n, const double* __restrict__ x, const double* __restrict__ y,
+                              const double* __restrict__ z, GhostGrid g, int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned) { atomicAdd(&count[cell], 1); });
+}
+
+// `fill` starts at zero; the within-cell order produced here is arbitrary and is made
+// deterministic by k_cell_canon afterwards.
+__global__ void k_ghost_scatter(int n, const double* __restrict__ x, const double* __restrict__ y,
+                                const double* __restrict__ z, GhostGrid g,
+                                const int* __restrict__ start, int* __restrict__ fill,
+                                int* __restrict__ entries) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned code) {
+        const int slot = start[cell] + atomicAdd(&fill[cell], 1);
+        entries[slot] = static_cast<int>(static_cast<unsigned>(i) | (code << GHOST_SHIFT));
+    });
+}
+
+__device__ __forceinline__ double image_shift(unsigned code2, double L) {
+    return code2 == 1u ? L : (code2 == 2u ? -L : 0.0);
+}
+
+__global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
+                               const double* __restrict__ x, const double* __restrict__ y,
+                               const double* __restrict__ z, const double* __restrict__ m,
+                               double G, double L, double4* __restrict__ rec) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_entries) return;
+    const unsigned e = static_cast<unsigned>(entries[p]);
+    const int i = static_cast<int>(e & GHOST_INDEX_MASK);
+    const unsigned code = e >> GHOST_SHIFT;
+    rec[p] = make_double4(x[i] + image_shift(code & 3u, L), y[i] + image_shift((code >> 2) & 3u, L),
+                          z[i] + image_shift((code >> 4) & 3u, L), G * m[i]);
+}
+
+// Targets = real (code 0) entries whose original index lies in [tgt_begin, tgt_begin+n_tgt).
+__global__ void k_target_flags(int n_entries, const int* __restrict__ entries, int tgt_begin,
+                               int n_tgt, int* __restrict__ flag) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n_entries) return;
+    int f = 0;
+    if (p < n_entries) {
+        const unsigned e = static_cast<unsigned>(entries[p]);
+        const int i = static_cast<int>(e & GHOST_INDEX_MASK);
+        f = ((e >> GHOST_SHIFT) == 0u && i >= tgt_begin && i < tgt_begin + n_tgt) ? 1 : 0;
+    }
+    flag[p] = f;  // entry n_entries is the trailing zero the scan needs
+}
+
+__global__ void k_target_scatter(int n_entries, const int* __restrict__ flag,
+                                 const int* __restrict__ slot, int* __restrict__ tlist) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_entries && flag[p]) tlist[slot[p]] = p;
+}
+
+// The accepted-pair arithmetic of src/particles.cpp:330-359 for one (target, source) pair with
+// r^2 <= cutoff_sq already established.
+template <bool SOFT0>
+__device__ __forceinline__ void p3m_accepted(double dx, double dy, double dz, double r2, double gm,
+                                             const PairConsts& k, double& ax, double& ay, double& az) {
+    auto cube = [&](double q) {
+        const double y = __builtin_amdgcn_rsq(q);
+        const double y2 = y * y;
+        const double h = __builtin_fma(-q, y2, 1.0);
+        const double y3 = y * y2;
+        return __builtin_fma(y3, h * __builtin_fma(k.c1875, h, k.c15), y3);
+    };
+    const double q1 = r2 + k.eps2;
+    double f1 = cube(q1);
+    if constexpr (SOFT0) f1 = (q1 > 0.0) ? f1 : 0.0;  // coincident particles, zero softening
+    double f = f1 - cube(r2 + k.eps_pm2);
+    if (r2 > k.r_switch_sq) {
+        const double dist = r2 * inv_sqrt_refined(r2);
+        const double t = (dist - k.r_switch) * k.inv_width;
+        f *= __builtin_fma(t * t, __builtin_fma(2.0, t, -3.0), 1.0);
+    }
+    const double s = gm * f;
+    ax = __builtin_fma(s, dx, ax);
+    ay = __builtin_fma(s, dy, ay);
+    az = __builtin_fma(s, dz, az);
+}
+
 struct P3MArgs {
-    const double* sx; const double* sy; const double* sz; const double* sgm;
-    const int* cell_start;   // [nside^3 + 1]
-    int nside;
-    int R;
-    double cell_scale;       // nside / L
-    const double* tx; const double* ty; const double* tz;
-    const int* tperm;
+    const double4* rec;      // sorted records incl. ghosts: {x, y, z, G*m}
+    const int* entries;      // original index | image code << 26
+    const int* cell_start;   // [np^3 + 1]
+    const int* tlist;        // sorted positions of the targets
+    int n_entries;
     int n_tgt;
+    int tgt_begin;
+    GhostGrid g;
     double* ax; double* ay; double* az;
     unsigned long long* accepted;   // optional counter of pairs with r^2 <= cutoff_sq
     PairConsts k;
 };
 
-__device__ __forceinline__ void p3m_run(const P3MArgs& a, int jb, int je, double xs, double ys,
-                                        double zs, double& ax, double& ay, double& az,
-                                        unsigned& hits) {
-    for (int j = jb; j < je; ++j) {
-        const double dx = a.sx[j] - xs, dy = a.sy[j] - ys, dz = a.sz[j] - zs;
-        const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-        if (r2 > a.k.cutoff_sq) continue;
-        ++hits;
-        double f = inv_cube_root2_guarded(r2 + a.k.eps2) - inv_cube_root2_guarded(r2 + a.k.eps_pm2);
-        if (r2 > a.k.r_switch_sq) {
-            const double dist = r2 * inv_sqrt_refined(r2);
-            const double t = (dist - a.k.r_switch) * a.k.inv_width;
-            f *= __builtin_fma(t * t, __builtin_fma(2.0, t, -3.0), 1.0);
-        }
-        const double s = a.sgm[j] * f;
-        ax = __builtin_fma(s, dx, ax);
-        ay = __builtin_fma(s, dy, ay);
-        az = __builtin_fma(s, dz, az);
-    }
-}
+constexpr int P3M_QCAP = 24;   // accepted-pair queue entries per lane (24 KiB LDS per workgroup)
 
+// One lane per target.  Two phases per lane, interleaved wave-wide:
+//   filter: walk the (2R+1)^2 runs, form r^2 for every candidate, push the sorted position of
+//           the ones inside the cutoff onto the lane's queue in LDS (cheap, ~25 % pass);
+//   drain:  when any lane's queue is full (and at the end), every lane evaluates its queued
+//           pairs with the full taper / double-softening arithmetic (dense: lanes hold similar
+//           numbers of entries).
+// Without the queue every candidate iteration in which ANY lane passes the cutoff pays for the
+// full pair function on all 64 lanes.
+template <bool SOFT0>
 __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
-    const int p = blockIdx.x * WG + threadIdx.x;
-    const bool live = p < a.n_tgt;
-    const int pc = live ? p : a.n_tgt - 1;
-    const double xi = a.tx[pc], yi = a.ty[pc], zi = a.tz[pc];
-    const int n = a.nside, R = a.R;
-    const double L = a.k.L;
-    const int cx = bin_coord(xi, a.cell_scale, n), cy = bin_coord(yi, a.cell_scale, n),
-              cz = bin_coord(zi, a.cell_scale, n);
+    __shared__ int queue[P3M_QCAP][WG];
+    const int t = blockIdx.x * WG + threadIdx.x;
+    const bool live = t < a.n_tgt;
+    const int p = a.tlist[live ? t : a.n_tgt - 1];
+    const double4 me = a.rec[p];
+    const GhostGrid g = a.g;
+    const PairConsts k = a.k;
+    const int pcx = bin_coord(me.x, g.scale, g.nside) + g.R;
+    const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
+    const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
     double ax = 0.0, ay = 0.0, az = 0.0;
+    int cnt = 0;
     unsigned hits = 0;
-    if (live) {
-        for (int oz = -R; oz <= R; ++oz) {
-            int z2 = cz + oz;
-            double zs = zi;
-            if (z2 < 0) { z2 += n; zs = zi + L; } else if (z2 >= n) { z2 -= n; zs = zi - L; }
-            for (int oy = -R; oy <= R; ++oy) {
-                int y2 = cy + oy;
-                double ys = yi;
-                if (y2 < 0) { y2 += n; ys = yi + L; } else if (y2 >= n) { y2 -= n; ys = yi - L; }
-                const int row = (z2 * n + y2) * n;
-                const int x0 = cx - R, x1 = cx + R;
-                const int m0 = x0 < 0 ? 0 : x0, m1 = x1 >= n ? n - 1 : x1;
-                p3m_run(a, a.cell_start[row + m0], a.cell_start[row + m1 + 1], xi, ys, zs, ax, ay, az, hits);
-                if (x0 < 0)   // sources in the top cells seen one box length lower
-                    p3m_run(a, a.cell_start[row + x0 + n], a.cell_start[row + n], xi + L, ys, zs, ax, ay, az, hits);
-                if (x1 >= n)  // sources in the bottom cells seen one box length higher
-                    p3m_run(a, a.cell_start[row], a.cell_start[row + x1 - n + 1], xi - L, ys, zs, ax, ay, az, hits);
+
+    auto drain = [&]() {
+        int most = cnt;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) most = max(most, __shfl_xor(most, d, 64));
+        for (int q = 0; q < most; ++q) {
+            if (q < cnt) {
+                const double4 s = a.rec[queue[q][threadIdx.x]];
+                const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+                p3m_accepted<SOFT0>(dx, dy, dz, r2, s.w, k, ax, ay, az);
             }
         }
-        const int o = a.tperm[p];
+        hits += cnt;
+        cnt = 0;
+    };
+
+    // Filter phase.  Lanes of a wavefront are neighbours along x, so their loads of the same
+    // run hit the same cache lines.  (Staging the union of the runs through LDS was measured
+    // slower: the loop is bound by instruction issue, not by the vector cache.)
+    const int span = 2 * g.R + 1;
+    for (int row = 0; row < span * span; ++row) {
+        const int ox = row / span - g.R, oy = row % span - g.R;
+        const int base = ((pcx + ox) * g.np + (pcy + oy)) * g.np + pcz;
+        int j = live ? a.cell_start[base - g.R] : 0;
+        const int je = live ? a.cell_start[base + g.R + 1] : 0;
+        while (__any(j < je)) {
+            if (j < je) {
+                const double4 s = a.rec[j];
+                const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+                if (!(r2 > k.cutoff_sq) && j != p) queue[cnt++][threadIdx.x] = j;
+                ++j;
+            }
+            if (__any(cnt == P3M_QCAP)) drain();
+        }
+    }
+    drain();
+
+    if (live) {
+        const int o = static_cast<int>(static_cast<unsigned>(a.entries[p]) & GHOST_INDEX_MASK) - a.tgt_begin;
         a.ax[o] += ax; a.ay[o] += ay; a.az[o] += az;
     }
     if (a.accepted) {
-        unsigned long long h = live ? hits - 1u : 0u;  // minus the target's own zero-distance entry
+        unsigned long long h = live ? hits : 0u;
         for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(a.accepted, h);
     }
