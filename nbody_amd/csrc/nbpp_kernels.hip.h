@@ -792,15 +792,23 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
         const int base = ((pcx + ox) * g.np + (pcy + oy)) * g.np + pcz;
         int j = live ? a.cell_start[base - g.R] : 0;
         const int je = live ? a.cell_start[base + g.R + 1] : 0;
-        while (__any(j < je)) {
-            if (j < je) {
-                const double4 s = a.rec[j];
-                const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+        while (__any(j < je)) {   // two candidates per lane per trip: half the loop overhead
+            const bool v0 = j < je, v1 = j + 1 < je;
+            double4 s0 = me, s1 = me;
+            if (v0) s0 = a.rec[j];
+            if (v1) s1 = a.rec[j + 1];
+            {
+                const double dx = s0.x - me.x, dy = s0.y - me.y, dz = s0.z - me.z;
                 const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-                if (!(r2 > k.cutoff_sq) && j != p) queue[cnt++][threadIdx.x] = j;
-                ++j;
+                if (v0 && !(r2 > k.cutoff_sq) && j != p) queue[cnt++][threadIdx.x] = j;
             }
-            if (__any(cnt == P3M_QCAP)) drain();
+            {
+                const double dx = s1.x - me.x, dy = s1.y - me.y, dz = s1.z - me.z;
+                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+                if (v1 && !(r2 > k.cutoff_sq) && j + 1 != p) queue[cnt++][threadIdx.x] = j + 1;
+            }
+            j += 2;
+            if (__any(cnt >= P3M_QCAP - 1)) drain();
         }
     }
     drain();
