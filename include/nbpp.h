@@ -97,8 +97,10 @@ enum {
     NBPP_OPT_TARGETS_PER_LANE = 3, /* all-pairs kernels: 0 = automatic, else 1, 2 or 4  */
     NBPP_OPT_SOURCE_SPLIT = 4,   /* all-pairs kernels: 0 = automatic, else the number of
                                     source slices summed separately (blockIdx.y)        */
-    NBPP_OPT_P3M_SEARCH_RADIUS = 5 /* P3M: cells per cutoff radius of the search grid,
+    NBPP_OPT_P3M_SEARCH_RADIUS = 5, /* P3M: cells per cutoff radius of the search grid,
                                     0 = automatic                                        */
+    NBPP_OPT_NO_EQUAL_MASS_PATH = 6 /* 1 = always multiply by the source mass per pair, even
+                                    when all masses are equal (testing)                  */
 };
 
 /*

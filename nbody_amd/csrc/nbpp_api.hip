@@ -84,14 +84,14 @@ struct Ctx {
     Buf part[3];                      // per-slice partial sums
     Buf host_in[4], host_acc[3];      // staging for the host-pointer entry point
     Buf canon[3];                     // P3M: positions brought into [0, L)
-    Buf blockmax, counter;
+    Buf blockmax, counter, massinfo;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0;
+            opt_p3m_radius = 0, opt_no_uniform = 0;
     nbpp_stats stats{};
     void release() {
         for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
                        &host_in[1], &host_in[2], &host_in[3], &host_acc[0], &host_acc[1],
-                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter})
+                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter, &massinfo})
             b->release();
         src.release();
         tgt.release();
@@ -214,8 +214,18 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
     g.src.npad = npad;
     for (Buf* b : {&g.src.x, &g.src.y, &g.src.z, &g.src.gm}) CHK(b->ensure(sizeof(double) * npad));
     CHK(g.src.box.ensure(sizeof(int) * 8 * (npad / SUB)));
+    // equal masses (every dark-matter particle of the reference has DM_PARTICLE_MASS,
+    // src/ics.cpp:209-212) are detected on the device; the pair kernel then skips the per-pair
+    // mass multiply
+    CHK(g.massinfo.ensure(16));
+    int* uniform_flag = g.massinfo.as<int>();
+    double* common_gm = reinterpret_cast<double*>(g.massinfo.as<char>() + 8);
+    hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(64), 0, s, 1, uniform_flag,
+                       (variant == NBPP_KERNEL_P3M_ALLPAIRS || g.opt_no_uniform) ? 0 : 1);
+    hipLaunchKernelGGL(k_mass_uniform, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, m, p->G,
+                       uniform_flag, common_gm);
     hipLaunchKernelGGL(k_gather_sources, dim3(npad / WG), dim3(WG), 0, s, n_src, npad,
-                       g.src.order.as<int>(), x, y, z, m, p->G, g.src.x.as<double>(),
+                       g.src.order.as<int>(), x, y, z, m, p->G, uniform_flag, g.src.x.as<double>(),
                        g.src.y.as<double>(), g.src.z.as<double>(), g.src.gm.as<double>());
     hipLaunchKernelGGL(k_source_boxes, dim3(npad / WG), dim3(WG), 0, s, npad,
                        g.src.x.as<double>(), g.src.y.as<double>(), g.src.z.as<double>(), k.qscale,
@@ -242,7 +252,9 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
 
     // launch shape: I targets per lane, source range split over blockIdx.y when the target
     // count alone cannot fill 256 CUs
-    int I = n_tgt >= (1 << 19) ? 4 : (n_tgt >= (1 << 17) ? 2 : 1);
+    // two targets per lane measured fastest at 128^3 (no spills at 4 waves/SIMD, fewer straddling
+    // sub-tiles than four); one per lane below 2^17 targets to keep more workgroups in flight
+    int I = n_tgt >= (1 << 17) ? 2 : 1;
     if (g.opt_force_i == 1 || g.opt_force_i == 2 || g.opt_force_i == 4) I = static_cast<int>(g.opt_force_i);
     const int blocks_i = cdiv(n_tgt, WG * I);
     const int n_tiles = npad / TJ;
@@ -258,6 +270,8 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
     a.tiles_per_split = tiles_per_split;
     a.ax = ax; a.ay = ay; a.az = az;
     a.n_tgt_pad = cdiv(n_tgt, 64) * 64;
+    a.uniform_mass = uniform_flag;
+    a.common_gm = common_gm;
     a.k = k;
     if (g.opt_timing) {
         CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
@@ -479,6 +493,7 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_TARGETS_PER_LANE: g.opt_force_i = value; return NBPP_OK;
         case NBPP_OPT_SOURCE_SPLIT: g.opt_force_split = value; return NBPP_OK;
         case NBPP_OPT_P3M_SEARCH_RADIUS: g.opt_p3m_radius = value; return NBPP_OK;
+        case NBPP_OPT_NO_EQUAL_MASS_PATH: g.opt_no_uniform = value; return NBPP_OK;
         default: return fail(NBPP_ERR_ARG, "unknown option key %d", key);
     }
 }

@@ -122,6 +122,27 @@ def test_direct_variants(lib, oracle, variant, per_lane):
     assert normalised_error(got, want) < TOL
 
 
+def test_equal_mass_path_matches_weighted_path(lib, oracle):
+    """Equal masses take the kernel variant that applies G*m once at the end; it must agree
+    with the per-pair-mass variant and with the oracle, including a ragged last tile."""
+    pos = datasets.zeldovich(16)
+    pos = [c[:4001].copy() for c in pos]
+    m = np.full(4001, 0.84 / 4001)
+    p = Config(MESH_SIZE=16, N_PER_SIDE=16, USE_PM=False).pp_params()
+    want = oracle.accumulate(p, *pos, m)
+    fast = gpu_acc(lib, p, pos, m)
+    lib.set_option(ffi.OPT_NO_EQUAL_MASS_PATH, 1)
+    try:
+        slow = gpu_acc(lib, p, pos, m)
+    finally:
+        lib.set_option(ffi.OPT_NO_EQUAL_MASS_PATH, 0)
+    assert normalised_error(fast, want) < TOL and normalised_error(slow, want) < TOL
+    assert normalised_error(fast, slow) < 1e-12
+    m2 = m.copy()
+    m2[-1] *= 1.0000001   # one unequal mass switches the whole call to the weighted path
+    assert normalised_error(gpu_acc(lib, p, pos, m2), oracle.accumulate(p, *pos, m2)) < TOL
+
+
 @pytest.mark.parametrize("split", [1, 3, 16])
 def test_direct_source_split_is_deterministic(lib, oracle, split):
     pos = datasets.clustered(5000)
