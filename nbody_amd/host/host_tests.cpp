@@ -6,6 +6,9 @@
 //   nbody_host_tests gpu-tests             known-answer tests on GPU 0, exit code = failures
 //   nbody_host_tests kdk <in.bin> <out.bin> <steps> <dt> <ini>
 //                                          PP-only KDK steps on particles read from in.bin
+//                                          (dt <= 0: the engine's adaptive time step)
+//   nbody_host_tests engine <in.bin> <out.bin> <steps> <dt> <ini>
+//                                          the same steps with the state resident on the GPU
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +18,7 @@
 #include <vector>
 
 #include "config.hpp"
+#include "device_engine.hpp"
 #include "integrator.hpp"
 #include "particles.hpp"
 
@@ -163,9 +167,13 @@ static void test_accumulate_and_contract() {
     REQUIRE(std::isinf(empty.get_gravity_timestep(config)));
 }
 
-static int run_kdk(const char* in_path, const char* out_path, int steps, double dt, const char* ini) {
+static int run_kdk(const char* in_path, const char* out_path, int steps, double dt, const char* ini,
+                   bool device_resident) {
     Config config;
     config.load(ini);
+    config.MAX_CYCLES = steps;
+    config.USE_ADAPTIVE_DT = !(dt > 0.0);
+    if (dt > 0.0) config.FIXED_DT = dt;
     FILE* f = std::fopen(in_path, "rb");
     if (!f) throw std::runtime_error("cannot open input");
     long long n = 0;
@@ -178,17 +186,33 @@ static int run_kdk(const char* in_path, const char* out_path, int steps, double 
         sys.add_particle(buf[i], buf[n + i], buf[2 * n + i], buf[3 * n + i], buf[4 * n + i],
                          buf[5 * n + i], buf[6 * n + i]);
     Cosmology cosmo;
-    update_cosmology(cosmo, config);
-    compute_pp_accelerations(sys, config);  // initial accelerations, as src/ics.cpp:305-346
-    for (int s = 0; s < steps; ++s) KDK_step(sys, cosmo, dt, config);
+    double last_dt = 0.0;
+    if (device_resident) {
+        nbpp_set_option(NBPP_OPT_TIMING, 1);
+        DeviceEngine engine(config, sys);
+        while (engine.cycle_count < steps) { last_dt = engine.current_dt; engine.step(); }
+        engine.download(sys);
+        cosmo = engine.cosmo;
+        std::printf("device-resident: %ld cycles, PP %.3f ms total\n", engine.cycle_count, engine.pp_ms);
+    } else {
+        update_cosmology(cosmo, config);
+        compute_pp_accelerations(sys, config);  // initial accelerations, as src/ics.cpp:305-346
+        double cur = config.USE_ADAPTIVE_DT ? std::min(sys.get_gravity_timestep(config), config.FIXED_DT)
+                                            : config.FIXED_DT;
+        for (int s = 0; s < steps; ++s) {
+            last_dt = cur;
+            KDK_step(sys, cosmo, cur, config);
+            if (config.USE_ADAPTIVE_DT) cur = std::min(sys.get_gravity_timestep(config), config.FIXED_DT);
+        }
+    }
     f = std::fopen(out_path, "wb");
     if (!f) throw std::runtime_error("cannot open output");
     std::fwrite(&n, sizeof(n), 1, f);
     for (auto* v : {&sys.pos_x, &sys.pos_y, &sys.pos_z, &sys.vel_x, &sys.vel_y, &sys.vel_z,
                     &sys.acc_x, &sys.acc_y, &sys.acc_z})
         std::fwrite(v->data(), sizeof(double), n, f);
-    const double tail[4] = {sys.max_accel_sq, cosmo.scale_factor, cosmo.hubble_param, cosmo.total_time};
-    std::fwrite(tail, sizeof(double), 4, f);
+    const double tail[5] = {sys.max_accel_sq, cosmo.scale_factor, cosmo.hubble_param, cosmo.total_time, last_dt};
+    std::fwrite(tail, sizeof(double), 5, f);
     std::fclose(f);
     return 0;
 }
@@ -201,15 +225,17 @@ int main(int argc, char** argv) {
             print_config(c);
             return 0;
         }
-        if (argc >= 2 && (!std::strcmp(argv[1], "gpu-tests") || !std::strcmp(argv[1], "kdk"))) {
+        if (argc >= 2 && (!std::strcmp(argv[1], "gpu-tests") || !std::strcmp(argv[1], "kdk") ||
+                          !std::strcmp(argv[1], "engine"))) {
             if (nbpp_init(0) != NBPP_OK) {
                 std::printf("nbpp_init failed: %s\n", nbpp_last_error());
                 return 2;
             }
             int rc = 0;
-            if (!std::strcmp(argv[1], "kdk")) {
-                if (argc < 7) throw std::runtime_error("kdk needs <in> <out> <steps> <dt> <ini>");
-                rc = run_kdk(argv[2], argv[3], std::atoi(argv[4]), std::atof(argv[5]), argv[6]);
+            if (std::strcmp(argv[1], "gpu-tests")) {
+                if (argc < 7) throw std::runtime_error("needs <in> <out> <steps> <dt> <ini>");
+                rc = run_kdk(argv[2], argv[3], std::atoi(argv[4]), std::atof(argv[5]), argv[6],
+                             !std::strcmp(argv[1], "engine"));
             } else {
                 test_pure_newtonian();
                 test_p3m_cutoff();
