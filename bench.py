@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--per-lane", type=int, default=0)
     ap.add_argument("--force-kernel", type=int, default=0)
     ap.add_argument("--p3m-radius", type=int, default=0)
+    ap.add_argument("--ordered", action="store_true",
+                    help="bitwise-reproducible ordered-pair kernel (NBPP_OPT_DETERMINISTIC)")
     args = ap.parse_args()
 
     import torch
@@ -88,6 +90,7 @@ def main():
     lib.set_option(ffi.OPT_TARGETS_PER_LANE, args.per_lane)
     lib.set_option(ffi.OPT_FORCE_KERNEL, args.force_kernel)
     lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, args.p3m_radius)
+    lib.set_option(ffi.OPT_DETERMINISTIC, 1 if args.ordered else 0)
 
     n_side = args.n_side
     n = n_side ** 3
@@ -111,8 +114,22 @@ def main():
         lib.accumulate_device(p, x, y, z, mm, ax, ay, az, tgt_begin=tgt_begin, n_tgt=n_tgt,
                               stream=stream)
 
+    def compute_pairs(x, y, z, mm, fx, fy, fz, part, n_parts):
+        lib.accumulate_pairs_device(p, x, y, z, mm, fx, fy, fz, part=part, n_parts=n_parts,
+                                    stream=stream)
+
+    from nbody_amd.distributed import force_evaluation_pairs
+    # direct summation on several GPUs: every unordered pair once, shared out over the ranks,
+    # accelerations combined by reduce-scatter; one GPU (or P3M): the ordinary entry point,
+    # which picks the same pair-once kernel by itself for a full direct evaluation
+    use_pairs = world > 1 and not use_pm and not args.ordered
+    work = [None]
+
     def step():
-        force_evaluation(parts, mass, acc, compute)
+        if use_pairs:
+            work[0] = force_evaluation_pairs(parts, mass, acc, compute_pairs, work[0])
+        else:
+            force_evaluation(parts, mass, acc, compute)
         return lib.stats()
 
     def fence():
@@ -156,7 +173,10 @@ def main():
             workload = f"PP direct summation fp64, N={n_side}^3, periodic box"
         value = pairs_per_step * args.steps / elapsed / 1e9
         # dominant kernel on rank 0's share: algorithmic flops of one launch / its duration
-        my_pairs = pairs_per_step * (counts[0] / n)
+        my_pairs = pairs_per_step / world if use_pairs else pairs_per_step * (counts[0] / n)
+        kernel_names = {1: "k_pairs (ordered pairs)", 2: "k_pairs (per-pair wrap)",
+                        3: "k_p3m_cells", 4: "k_pairs (P3M, all pairs)",
+                        5: "k_pairs_sym (each unordered pair once, both directions)"}
         achieved = my_pairs * flops / (kernel_avg_ms * 1e-3) / 1e12
         # HBM bytes per launch come from the committed rocprofv3 counter passes of this same
         # command (FETCH_SIZE doubled as the gfx950 correction requires, plus WRITE_SIZE)
@@ -173,6 +193,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_particles": n, "parallelism": f"i-partition x{world}",
                        "flops_per_interaction": flops,
+                       "kernel": kernel_names.get(st.get("kernel_variant"), "?"),
                        "pct_fp64_vector_peak": 100.0 * value * 1e9 * flops / (world * FP64_VECTOR_PEAK_TFLOPS * 1e12)},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,

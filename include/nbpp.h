@@ -87,7 +87,10 @@ enum {
     NBPP_KERNEL_DIRECT = 1,       /* all-pairs, tiles classified for the image shift   */
     NBPP_KERNEL_DIRECT_WRAP = 2,  /* all-pairs, per-pair minimum image everywhere      */
     NBPP_KERNEL_P3M_CELLS = 3,    /* counting-sort cell list, cutoff-bounded search    */
-    NBPP_KERNEL_P3M_ALLPAIRS = 4  /* P3M pair function over all pairs (small n, tests) */
+    NBPP_KERNEL_P3M_ALLPAIRS = 4, /* P3M pair function over all pairs (small n, tests) */
+    NBPP_KERNEL_DIRECT_SYMMETRIC = 5 /* all-pairs, each unordered pair evaluated once and
+                                     applied in both directions (fp64 atomics: results are
+                                     not bitwise reproducible from run to run)          */
 };
 
 /* nbpp_set_option keys */
@@ -99,8 +102,10 @@ enum {
                                     source slices summed separately (blockIdx.y)        */
     NBPP_OPT_P3M_SEARCH_RADIUS = 5, /* P3M: cells per cutoff radius of the search grid,
                                     0 = automatic                                        */
-    NBPP_OPT_NO_EQUAL_MASS_PATH = 6 /* 1 = always multiply by the source mass per pair, even
+    NBPP_OPT_NO_EQUAL_MASS_PATH = 6, /* 1 = always multiply by the source mass per pair, even
                                     when all masses are equal (testing)                  */
+    NBPP_OPT_DETERMINISTIC = 7   /* 1 = never pick NBPP_KERNEL_DIRECT_SYMMETRIC by itself:
+                                    results are then bitwise reproducible from run to run */
 };
 
 /*
@@ -141,6 +146,21 @@ int nbpp_accumulate_device(const nbpp_params* p, size_t n_src,
                            const double* x, const double* y, const double* z,
                            const double* m, size_t tgt_begin, size_t n_tgt,
                            double* ax, double* ay, double* az, void* stream);
+
+/*
+ * One share of a direct-summation (use_pm == 0) evaluation, for multi-GPU runs that use every
+ * pair once: the unordered pairs {i, j} of the n particles are divided into n_parts equal
+ * shares; this call evaluates share `part` and adds BOTH a_i and a_j of each of its pairs into
+ * ax, ay, az, which are DEVICE arrays of full length n in the caller's particle order.  The
+ * sum of the arrays over all parts (e.g. an RCCL reduce-scatter) is the complete acceleration;
+ * with n_parts == 1 the call is equivalent to nbpp_accumulate_device over all targets.
+ * Uses fp64 atomics: not bitwise reproducible from run to run.  No counterpart in the
+ * reference, which evaluates every ordered pair (src/particles.cpp:270-365).
+ */
+int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n,
+                                 const double* x, const double* y, const double* z,
+                                 const double* m, int part, int n_parts,
+                                 double* ax, double* ay, double* az, void* stream);
 
 /*
  * Device-resident pieces of the caller contract around the hot path.  All pointers are

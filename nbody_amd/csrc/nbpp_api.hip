@@ -13,6 +13,7 @@
 
 #include "../../include/nbpp.h"
 #include "nbpp_kernels.hip.h"
+#include "nbpp_sym.hip.h"
 
 using namespace nbpp;
 
@@ -86,7 +87,7 @@ struct Ctx {
     Buf canon[3];                     // P3M: positions brought into [0, L)
     Buf blockmax, counter, massinfo;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0, opt_no_uniform = 0;
+            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0;
     nbpp_stats stats{};
     void release() {
         for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
@@ -204,7 +205,7 @@ int launch_pairs(int mode, bool soft0, int I, dim3 grid, const PairArgs& a, hipS
 // All-pairs path (direct summation, or the P3M pair function over all pairs).
 int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, const double* y,
                  const double* z, const double* m, int tgt_begin, int n_tgt, double* ax,
-                 double* ay, double* az, hipStream_t s) {
+                 double* ay, double* az, hipStream_t s, int sym_part = 0, int sym_parts = 1) {
     const PairConsts k = make_consts(p);
     const BinGrid grid = direct_grid(n_src, p->domain_size);
 
@@ -231,6 +232,41 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
                        g.src.x.as<double>(), g.src.y.as<double>(), g.src.z.as<double>(), k.qscale,
                        g.src.box.as<int>());
     HIPCHK(hipGetLastError());
+
+    if (variant == NBPP_KERNEL_DIRECT_SYMMETRIC) {
+        if (g.opt_timing) {
+            CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
+            HIPCHK(hipEventRecord(g.ev[1], s));
+        }
+        // four particles per lane measured fastest (fewest rotations per pair); fewer when the
+        // particle count cannot give every CU four workgroups of groups
+        int I = n_src >= (1 << 20) ? 4 : (n_src >= (1 << 19) ? 2 : 1);
+        if (g.opt_force_i == 1 || g.opt_force_i == 2 || g.opt_force_i == 4) I = static_cast<int>(g.opt_force_i);
+        SymArgs a{};
+        a.sx = g.src.x.as<double>(); a.sy = g.src.y.as<double>(); a.sz = g.src.z.as<double>();
+        a.sgm = g.src.gm.as<double>(); a.sbox = g.src.box.as<int>(); a.order = g.src.order.as<int>();
+        a.n = n_src; a.n_tiles = npad / 64;
+        const int NG = a.n_tiles / I;
+        const int parts = std::max(1, sym_parts), part = std::min(sym_part, parts - 1);
+        a.group_begin = static_cast<int>(1LL * NG * part / parts);
+        a.group_end = static_cast<int>(1LL * NG * (part + 1) / parts);
+        a.ax = ax; a.ay = ay; a.az = az;
+        a.uniform_mass = uniform_flag; a.common_gm = common_gm;
+        a.tile_counts = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
+        a.k = k;
+        const int blocks = cdiv(a.group_end - a.group_begin, WG / 64);
+        const bool soft0 = p->soft_sq == 0.0;
+        if (blocks > 0) {
+            if (I == 1) { if (soft0) hipLaunchKernelGGL((k_pairs_sym<1, true>), dim3(blocks), dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<1, false>), dim3(blocks), dim3(WG), 0, s, a); }
+            else if (I == 2) { if (soft0) hipLaunchKernelGGL((k_pairs_sym<2, true>), dim3(blocks), dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<2, false>), dim3(blocks), dim3(WG), 0, s, a); }
+            else { if (soft0) hipLaunchKernelGGL((k_pairs_sym<4, true>), dim3(blocks), dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<4, false>), dim3(blocks), dim3(WG), 0, s, a); }
+            HIPCHK(hipGetLastError());
+        }
+        g.stats.pairs_evaluated = static_cast<uint64_t>(n_src) * static_cast<uint64_t>(n_src - 1) / parts;
+        g.stats.pair_launches = 1;
+        return NBPP_OK;
+    }
 
     // targets: the sources themselves, or a separately sorted slice
     const double *tx, *ty, *tz;
@@ -393,7 +429,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
 
 int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const double* y,
                       const double* z, const double* m, size_t tgt_begin, size_t n_tgt,
-                      double* ax, double* ay, double* az, hipStream_t s) {
+                      double* ax, double* ay, double* az, hipStream_t s, int sym_part = -1,
+                      int sym_parts = 1) {
     if (n_src > 0x7fffff00ULL) return fail(NBPP_ERR_RANGE, "n_src exceeds 2^31 - 256");
     g.stats = nbpp_stats{};
     g.stats.n_sources = n_src;
@@ -410,6 +447,13 @@ int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const
     } else {
         variant = NBPP_KERNEL_DIRECT;
         if (g.opt_force_kernel == NBPP_KERNEL_DIRECT_WRAP) variant = NBPP_KERNEL_DIRECT_WRAP;
+        const bool all_targets = tgt_begin == 0 && n_tgt == n_src;
+        // each unordered pair once: chosen by itself for large full evaluations (the ordered
+        // kernel needs n_tgt alone to fill the GPU; below 2^19 its source split does better)
+        if (all_targets && (g.opt_force_kernel == NBPP_KERNEL_DIRECT_SYMMETRIC ||
+                            (g.opt_force_kernel == 0 && !g.opt_deterministic && n_src >= (1u << 19))))
+            variant = NBPP_KERNEL_DIRECT_SYMMETRIC;
+        if (sym_part >= 0) variant = NBPP_KERNEL_DIRECT_SYMMETRIC;
     }
     g.stats.kernel_variant = variant;
     if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[0], s));
@@ -418,7 +462,8 @@ int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const
                           static_cast<int>(n_tgt), ax, ay, az, s));
     } else {
         CHK(run_allpairs(p, variant, static_cast<int>(n_src), x, y, z, m,
-                         static_cast<int>(tgt_begin), static_cast<int>(n_tgt), ax, ay, az, s));
+                         static_cast<int>(tgt_begin), static_cast<int>(n_tgt), ax, ay, az, s,
+                         std::max(sym_part, 0), sym_parts));
     }
     if (g.opt_timing) {
         HIPCHK(hipEventRecord(g.ev[2], s));
@@ -494,6 +539,7 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_SOURCE_SPLIT: g.opt_force_split = value; return NBPP_OK;
         case NBPP_OPT_P3M_SEARCH_RADIUS: g.opt_p3m_radius = value; return NBPP_OK;
         case NBPP_OPT_NO_EQUAL_MASS_PATH: g.opt_no_uniform = value; return NBPP_OK;
+        case NBPP_OPT_DETERMINISTIC: g.opt_deterministic = value; return NBPP_OK;
         default: return fail(NBPP_ERR_ARG, "unknown option key %d", key);
     }
 }
@@ -518,6 +564,22 @@ int nbpp_accumulate_device(const nbpp_params* p, size_t n_src, const double* x, 
     HIPCHK(hipSetDevice(g.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
     return compute_on_device(p, n_src, x, y, z, m, tgt_begin, n_tgt, ax, ay, az, s);
+}
+
+int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n, const double* x, const double* y,
+                                 const double* z, const double* m, int part, int n_parts,
+                                 double* ax, double* ay, double* az, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    CHK(check_params(p));
+    if (p->use_pm) return fail(NBPP_ERR_ARG, "nbpp_accumulate_pairs_device is for use_pm == 0 only");
+    if (n_parts < 1 || part < 0 || part >= n_parts)
+        return fail(NBPP_ERR_ARG, "part %d is not in [0, %d)", part, n_parts);
+    if (n == 0) return NBPP_OK;
+    if (!x || !y || !z || !m || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    std::lock_guard<std::mutex> lock(g_mu);
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    return compute_on_device(p, n, x, y, z, m, 0, n, ax, ay, az, s, part, n_parts);
 }
 
 int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const double* y,

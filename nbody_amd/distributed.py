@@ -98,3 +98,43 @@ def force_evaluation(parts: SlicedParticles, mass_all: torch.Tensor,
     for a in acc:
         a.zero_()
     compute(x, y, z, mass_all, acc[0], acc[1], acc[2], parts.begin, parts.count)
+
+
+def force_evaluation_pairs(parts: SlicedParticles, mass_all: torch.Tensor,
+                           acc: Sequence[torch.Tensor], compute_pairs: Callable,
+                           work: List[torch.Tensor] | None = None) -> List[torch.Tensor]:
+    """One direct-summation evaluation that uses every unordered pair once across the ranks.
+
+    `compute_pairs(x, y, z, m, fx, fy, fz, part, n_parts)` adds, for this rank's share of the
+    pairs, the accelerations of BOTH members of each pair into the full-length fx/fy/fz
+    (Library.accumulate_pairs_device on a GPU).  The shares are then summed across ranks with a
+    reduce-scatter, which leaves every rank with the complete accelerations of its own slice in
+    `acc` (overwritten: PP-only mode starts from zero, src/integrator.cpp:246-251).
+
+    `work` are three reusable buffers of stride*world elements (returned for reuse)."""
+    x, y, z = parts.gather_positions()
+    total = parts.stride * parts.world
+    if work is None:
+        work = [torch.empty(total, dtype=x.dtype, device=parts.device) for _ in range(3)]
+    exact = parts.n % parts.world == 0      # slices are equal: padded layout == global layout
+    full = work if exact else [torch.empty(parts.n, dtype=x.dtype, device=parts.device) for _ in range(3)]
+    for f in full:
+        f.zero_()
+    compute_pairs(x, y, z, mass_all, full[0], full[1], full[2], parts.rank, parts.world)
+    for c in range(3):
+        if parts.world == 1:
+            acc[c].copy_(full[c][: parts.count])
+            continue
+        if not exact:   # expand to the rank-major padded layout the collective needs
+            work[c].zero_()
+            for r in range(parts.world):
+                work[c][r * parts.stride: r * parts.stride + parts.counts[r]] = \
+                    full[c][parts.begins[r]: parts.begins[r] + parts.counts[r]]
+        out = torch.empty(parts.stride, dtype=x.dtype, device=parts.device)
+        try:
+            dist.reduce_scatter_tensor(out, work[c])
+        except RuntimeError:            # backends without reduce-scatter (gloo): all-reduce
+            dist.all_reduce(work[c])
+            out = work[c][parts.rank * parts.stride: (parts.rank + 1) * parts.stride]
+        acc[c].copy_(out[: parts.count])
+    return work

@@ -9,13 +9,14 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libnbpp.so")
 
-KERNEL_NONE, KERNEL_DIRECT, KERNEL_DIRECT_WRAP, KERNEL_P3M_CELLS, KERNEL_P3M_ALLPAIRS = range(5)
+KERNEL_NONE, KERNEL_DIRECT, KERNEL_DIRECT_WRAP, KERNEL_P3M_CELLS, KERNEL_P3M_ALLPAIRS, \
+    KERNEL_DIRECT_SYMMETRIC = range(6)
 OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SEARCH_RADIUS, \
-    OPT_NO_EQUAL_MASS_PATH = 1, 2, 3, 4, 5, 6
+    OPT_NO_EQUAL_MASS_PATH, OPT_DETERMINISTIC = 1, 2, 3, 4, 5, 6, 7
 
 EXPORTS = (
     "nbpp_init", "nbpp_shutdown", "nbpp_last_error", "nbpp_set_option", "nbpp_get_stats",
-    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_kick_device", "nbpp_drift_device",
+    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device",
     "nbpp_max_accel_sq_device",
 )
 
@@ -88,6 +89,8 @@ class Library:
         L.nbpp_accumulate.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7
         L.nbpp_accumulate_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 4 + [
             C.c_size_t, C.c_size_t] + [_DP] * 3 + [C.c_void_p]
+        L.nbpp_accumulate_pairs_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 4 + [
+            C.c_int, C.c_int] + [_DP] * 3 + [C.c_void_p]
         L.nbpp_kick_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 3 + [C.c_void_p]
         L.nbpp_drift_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 2 + [C.c_void_p]
         L.nbpp_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
@@ -132,6 +135,16 @@ class Library:
             raise ValueError("acceleration arrays shorter than the target count")
         self._check(self.lib.nbpp_accumulate_device(
             C.byref(p), n_src, _dev(x), _dev(y), _dev(z), _dev(m), tgt_begin, n_tgt,
+            _dev(ax), _dev(ay), _dev(az), C.c_void_p(stream or 0)))
+
+    def accumulate_pairs_device(self, p, x, y, z, m, ax, ay, az, part=0, n_parts=1, stream=None):
+        """Share `part` of `n_parts` of all unordered pairs into full-length ax/ay/az
+        (nbpp_accumulate_pairs_device)."""
+        n = x.numel()
+        if min(ax.numel(), ay.numel(), az.numel()) < n:
+            raise ValueError("acceleration arrays must hold all n particles")
+        self._check(self.lib.nbpp_accumulate_pairs_device(
+            C.byref(p), n, _dev(x), _dev(y), _dev(z), _dev(m), part, n_parts,
             _dev(ax), _dev(ay), _dev(az), C.c_void_p(stream or 0)))
 
     # caller contract ---------------------------------------------------------------

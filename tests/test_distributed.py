@@ -50,6 +50,25 @@ def _worker(rank, world, port, n, use_pm, out_dir):
     for _ in range(2):  # twice: buffers are reused between evaluations
         force_evaluation(parts, mass, acc, compute)
     assert torch.equal(mass, torch.from_numpy(m))
+
+    if not use_pm:
+        # the pair-once path: each rank fills a full-length array with its share, here "the
+        # accelerations of my own slice", and the reduce-scatter must hand every rank its slice
+        from nbody_amd.distributed import force_evaluation_pairs
+
+        def compute_pairs(x, y, z, mm, fx, fy, fz, part, n_parts):
+            b, c = parts.begins[part], parts.counts[part]
+            got = orc.accumulate(p, x.numpy(), y.numpy(), z.numpy(), mm.numpy(), tgt_begin=b,
+                                 n_tgt=c, nthreads=2)
+            for dst, src in zip((fx, fy, fz), got):
+                dst[b:b + c] += torch.from_numpy(src)
+
+        acc2 = [torch.full((parts.count,), -3.0, dtype=torch.float64) for _ in range(3)]
+        work = None
+        for _ in range(2):
+            work = force_evaluation_pairs(parts, mass, acc2, compute_pairs, work)
+        for a1, a2 in zip(acc, acc2):
+            assert torch.equal(a1, a2)
     np.save(os.path.join(out_dir, f"acc_{rank}.npy"), np.stack([a.numpy() for a in acc]))
     dist.barrier()
     dist.destroy_process_group()

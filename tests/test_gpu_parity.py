@@ -122,6 +122,50 @@ def test_direct_variants(lib, oracle, variant, per_lane):
     assert normalised_error(got, want) < TOL
 
 
+@pytest.mark.parametrize("per_lane", [1, 2, 4])
+@pytest.mark.parametrize("equal_mass", [True, False])
+def test_symmetric_kernel(lib, oracle, per_lane, equal_mass):
+    """Every unordered pair evaluated once, applied in both directions (fp64 atomics)."""
+    for pos in (datasets.zeldovich(16), datasets.clustered(5003), datasets.uniform_random(700),
+                datasets.jittered_lattice(12, jitter=0.0)):
+        n = pos[0].size
+        m = datasets.masses(n, equal=equal_mass)
+        p = Config(MESH_SIZE=16, N_PER_SIDE=16, USE_PM=False).pp_params()
+        want = oracle.accumulate(p, *pos, m)
+        lib.set_option(ffi.OPT_FORCE_KERNEL, ffi.KERNEL_DIRECT_SYMMETRIC)
+        lib.set_option(ffi.OPT_TARGETS_PER_LANE, per_lane)
+        try:
+            rng = np.random.default_rng(n)
+            acc0 = [rng.standard_normal(n) * 1e-3 for _ in range(3)]
+            got = gpu_acc(lib, p, pos, m, acc0)
+            assert lib.stats()["kernel_variant"] == ffi.KERNEL_DIRECT_SYMMETRIC
+        finally:
+            lib.set_option(ffi.OPT_FORCE_KERNEL, 0)
+            lib.set_option(ffi.OPT_TARGETS_PER_LANE, 0)
+        want = [w + a for w, a in zip(want, acc0)]
+        assert normalised_error(got, want, pair_force_scale(p, m, n)) < TOL
+
+
+@pytest.mark.parametrize("n_parts", [1, 3, 8])
+def test_pair_shares_sum_to_the_full_evaluation(lib, oracle, n_parts):
+    """nbpp_accumulate_pairs_device: the shares a multi-GPU run hands to its ranks, evaluated one
+    after the other on one GPU into the same arrays, must add up to the complete accelerations."""
+    import torch
+    n = 9001
+    pos = datasets.clustered(n)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=16, N_PER_SIDE=21, USE_PM=False).pp_params()
+    want = oracle.accumulate(p, *pos, m)
+    x, y, z, mm = _t(pos + [m])
+    acc = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    for part in range(n_parts):
+        lib.accumulate_pairs_device(p, x, y, z, mm, *acc, part=part, n_parts=n_parts)
+    torch.cuda.synchronize()
+    assert normalised_error([a.cpu().numpy() for a in acc], want) < TOL
+    with pytest.raises(ffi.NbppError):
+        lib.accumulate_pairs_device(p, x, y, z, mm, *acc, part=3, n_parts=3)
+
+
 def test_equal_mass_path_matches_weighted_path(lib, oracle):
     """Equal masses take the kernel variant that applies G*m once at the end; it must agree
     with the per-pair-mass variant and with the oracle, including a ragged last tile."""
