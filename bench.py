@@ -178,6 +178,10 @@ def main():
                         3: "k_p3m_cells", 4: "k_pairs (P3M, all pairs)",
                         5: "k_pairs_sym (each unordered pair once, both directions)"}
         achieved = my_pairs * flops / (kernel_avg_ms * 1e-3) / 1e12
+        # fp64 flops the kernel really issues per ordered interaction (FMA = 2, rsqrt = 1):
+        # ordered kernel 25 (no per-pair wrap, +6 for the rsqrt refinement); the pair-once
+        # kernel issues 31 per unordered pair
+        executed = {1: 25.0, 2: 31.0, 5: 15.5}.get(st.get("kernel_variant"))
         # HBM bytes per launch come from the committed rocprofv3 counter passes of this same
         # command (FETCH_SIZE doubled as the gfx950 correction requires, plus WRITE_SIZE)
         traffic = None
@@ -197,6 +201,9 @@ def main():
                        "pct_fp64_vector_peak": 100.0 * value * 1e9 * flops / (world * FP64_VECTOR_PEAK_TFLOPS * 1e12)},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                         "executed_flops_per_interaction": executed,
+                         "executed_frac": (achieved * executed / flops / FP64_VECTOR_PEAK_TFLOPS
+                                           if executed else None),
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC)",
                          "algorithmic_bytes": 56.0 * n, "kernel_ms": kernel_avg_ms,
                          "prepare_ms": float(np.mean(prep_ms)),
