@@ -7,6 +7,8 @@
 //   nbody_host_tests kdk <in.bin> <out.bin> <steps> <dt> <ini>
 //                                          PP-only KDK steps on particles read from in.bin
 //                                          (dt <= 0: the engine's adaptive time step)
+//   nbody_host_tests ics <ini> <out.bin>   Zel'dovich particles of <ini> (x y z vx vy vz), GPU FFT
+//   nbody_host_tests run <ini> <cycles>    ICs + device-resident engine for <cycles> steps
 //   nbody_host_tests engine <in.bin> <out.bin> <steps> <dt> <ini>
 //                                          the same steps with the state resident on the GPU
 #include <cmath>
@@ -19,6 +21,7 @@
 
 #include "config.hpp"
 #include "device_engine.hpp"
+#include "ics.hpp"
 #include "integrator.hpp"
 #include "particles.hpp"
 
@@ -223,6 +226,39 @@ int main(int argc, char** argv) {
             Config c;
             if (argc >= 3) c.load(argv[2]);
             print_config(c);
+            return 0;
+        }
+        if (argc >= 4 && !std::strcmp(argv[1], "ics")) {
+            Config config;
+            config.load(argv[2]);
+            Cosmology cosmo;
+            ParticleSystem dm = initialize_particles(config, cosmo);
+            FILE* f = std::fopen(argv[3], "wb");
+            if (!f) throw std::runtime_error("cannot open output");
+            long long n = static_cast<long long>(dm.num_particles);
+            std::fwrite(&n, sizeof(n), 1, f);
+            for (auto* v : {&dm.pos_x, &dm.pos_y, &dm.pos_z, &dm.vel_x, &dm.vel_y, &dm.vel_z})
+                std::fwrite(v->data(), sizeof(double), n, f);
+            const double tail[2] = {cosmo.scale_factor, cosmo.hubble_param};
+            std::fwrite(tail, sizeof(double), 2, f);
+            std::fclose(f);
+            return 0;
+        }
+        if (argc >= 4 && !std::strcmp(argv[1], "run")) {
+            if (nbpp_init(0) != NBPP_OK) { std::printf("nbpp_init failed: %s\n", nbpp_last_error()); return 2; }
+            nbpp_set_option(NBPP_OPT_TIMING, 1);
+            Config config;
+            config.load(argv[2]);
+            config.MAX_CYCLES = std::atoi(argv[3]);
+            Cosmology cosmo;
+            ParticleSystem dm = initialize_particles(config, cosmo);
+            DeviceEngine engine(config, dm);
+            std::printf("cycle 0: a=%.6f dt=%.6e max|a|^2=%.6e\n", engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq);
+            const ExitStatus st = engine.run();
+            std::printf("cycle %ld: a=%.6f dt=%.6e max|a|^2=%.6e  PP %.3f ms/cycle  exit=%d\n", engine.cycle_count,
+                        engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq,
+                        engine.pp_ms / (engine.cycle_count + 1), static_cast<int>(st));
+            nbpp_shutdown();
             return 0;
         }
         if (argc >= 2 && (!std::strcmp(argv[1], "gpu-tests") || !std::strcmp(argv[1], "kdk") ||

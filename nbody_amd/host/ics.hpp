@@ -1,0 +1,30 @@
+// ics.hpp - Zel'dovich initial conditions for the dark matter, restating the reference's
+// compute_zeldovich_field and initialize_dm (src/ics.cpp:10-216): BBKS spectrum normalised to
+// sigma_8, Gaussian white noise from std::default_random_engine + std::normal_distribution
+// (the same standard-library stream the reference draws), displacement field by FFT, particles on
+// a lattice displaced by the field.  The three-dimensional transforms run on the GPU (hipFFT).
+#pragma once
+#include <vector>
+
+#include "config.hpp"
+#include "integrator.hpp"
+#include "particles.hpp"
+
+namespace nbh {
+
+struct ZeldovichField {          // src/ics.h
+    std::vector<double> dx, dy, dz;   // MESH_SIZE^3 each, index (ix*M + iy)*M + iz
+    double f = 0.0;                   // growth rate Omega_m(a)^0.55
+};
+
+ZeldovichField compute_zeldovich_field(double scale_factor, const Config& config);   // :36-165
+
+// Lattice + displacement particles with Zel'dovich velocities (src/ics.cpp:167-216).
+void initialize_dm(ParticleSystem& dm, const Cosmology& cosmo, const Config& config,
+                   const ZeldovichField& zf);
+
+// The dark-matter part of initialize_state (src/ics.cpp:290-300): cosmology at t = 0, field,
+// particles.  Accelerations are left at zero; the engine computes them.
+ParticleSystem initialize_particles(const Config& config, Cosmology& cosmo);
+
+}  // namespace nbh
