@@ -48,6 +48,10 @@ __device__ __forceinline__ double rotate_lane(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// (Moving the coordinates through the LDS crossbar instead, ds_bpermute_b32 issued at the start
+// of a step, was measured slower: the extra live registers spill at 4 waves/SIMD and 3 waves/SIMD
+// loses more than the six DPP moves cost.)
+
 // One evaluation, both directions.  (dx,dy,dz) points from i to j.
 template <bool SOFT0, bool WEIGHTED>
 __device__ __forceinline__ void pair_both(double dx, double dy, double dz, double wi, double wj,
