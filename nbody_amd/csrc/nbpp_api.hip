@@ -239,9 +239,9 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
             HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
             HIPCHK(hipEventRecord(g.ev[1], s));
         }
-        // four particles per lane measured fastest (fewest rotations per pair); fewer when the
-        // particle count cannot give every CU four workgroups of groups
-        int I = n_src >= (1 << 20) ? 4 : (n_src >= (1 << 19) ? 2 : 1);
+        // four particles per lane (fewest rotations per pair) unless there are too few particles
+        // to form groups of 256
+        int I = n_src >= (1 << 16) ? 4 : (n_src >= (1 << 14) ? 2 : 1);
         if (g.opt_force_i == 1 || g.opt_force_i == 2 || g.opt_force_i == 4) I = static_cast<int>(g.opt_force_i);
         SymArgs a{};
         a.sx = g.src.x.as<double>(); a.sy = g.src.y.as<double>(); a.sz = g.src.z.as<double>();
@@ -249,20 +249,24 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
         a.n = n_src; a.n_tiles = npad / 64;
         const int NG = a.n_tiles / I;
         const int parts = std::max(1, sym_parts), part = std::min(sym_part, parts - 1);
-        a.group_begin = static_cast<int>(1LL * NG * part / parts);
-        a.group_end = static_cast<int>(1LL * NG * (part + 1) / parts);
+        // every group's visit list is cut into parts * local slices: `parts` shares for the ranks of
+        // a multi-GPU run, and enough local slices (blockIdx.y) for ~16 wavefronts per SIMD-slot
+        const int visits_per_group = std::max(1, ((NG - 1) / 2) * I);
+        int local = std::max(1, cdiv(16384, NG));
+        if (g.opt_force_split > 0) local = static_cast<int>(g.opt_force_split);
+        local = std::max(1, std::min(local, visits_per_group / parts));
+        a.n_slices = parts * local;
+        a.slice_begin = part * local;
         a.ax = ax; a.ay = ay; a.az = az;
         a.uniform_mass = uniform_flag; a.common_gm = common_gm;
         a.tile_counts = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
         a.k = k;
-        const int blocks = cdiv(a.group_end - a.group_begin, WG / 64);
+        const dim3 grid(cdiv(NG, WG / 64), local);
         const bool soft0 = p->soft_sq == 0.0;
-        if (blocks > 0) {
-            if (I == 1) { if (soft0) hipLaunchKernelGGL((k_pairs_sym<1, true>), dim3(blocks), dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<1, false>), dim3(blocks), dim3(WG), 0, s, a); }
-            else if (I == 2) { if (soft0) hipLaunchKernelGGL((k_pairs_sym<2, true>), dim3(blocks), dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<2, false>), dim3(blocks), dim3(WG), 0, s, a); }
-            else { if (soft0) hipLaunchKernelGGL((k_pairs_sym<4, true>), dim3(blocks), dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<4, false>), dim3(blocks), dim3(WG), 0, s, a); }
-            HIPCHK(hipGetLastError());
-        }
+        if (I == 1) { if (soft0) hipLaunchKernelGGL((k_pairs_sym<1, true>), grid, dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<1, false>), grid, dim3(WG), 0, s, a); }
+        else if (I == 2) { if (soft0) hipLaunchKernelGGL((k_pairs_sym<2, true>), grid, dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<2, false>), grid, dim3(WG), 0, s, a); }
+        else { if (soft0) hipLaunchKernelGGL((k_pairs_sym<4, true>), grid, dim3(WG), 0, s, a); else hipLaunchKernelGGL((k_pairs_sym<4, false>), grid, dim3(WG), 0, s, a); }
+        HIPCHK(hipGetLastError());
         g.stats.pairs_evaluated = static_cast<uint64_t>(n_src) * static_cast<uint64_t>(n_src - 1) / parts;
         g.stats.pair_launches = 1;
         return NBPP_OK;
@@ -448,10 +452,10 @@ int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const
         variant = NBPP_KERNEL_DIRECT;
         if (g.opt_force_kernel == NBPP_KERNEL_DIRECT_WRAP) variant = NBPP_KERNEL_DIRECT_WRAP;
         const bool all_targets = tgt_begin == 0 && n_tgt == n_src;
-        // each unordered pair once: chosen by itself for large full evaluations (the ordered
-        // kernel needs n_tgt alone to fill the GPU; below 2^19 its source split does better)
+        // each unordered pair once: chosen by itself for full evaluations of 2^14 particles or
+        // more (measured faster than the ordered kernel from 32^3 up, equal at 16^3)
         if (all_targets && (g.opt_force_kernel == NBPP_KERNEL_DIRECT_SYMMETRIC ||
-                            (g.opt_force_kernel == 0 && !g.opt_deterministic && n_src >= (1u << 19))))
+                            (g.opt_force_kernel == 0 && !g.opt_deterministic && n_src >= (1u << 14))))
             variant = NBPP_KERNEL_DIRECT_SYMMETRIC;
         if (sym_part >= 0) variant = NBPP_KERNEL_DIRECT_SYMMETRIC;
     }

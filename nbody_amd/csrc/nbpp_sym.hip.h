@@ -30,8 +30,12 @@ struct SymArgs {
     const int* order;       // sorted -> original index
     int n;                  // real particles (sorted entries beyond n are zero-weight padding)
     int n_tiles;            // padded count / 64, a multiple of I
-    int group_begin;        // groups [group_begin, group_end) are handled by this launch
-    int group_end;
+    // The visit list of every group is cut into n_slices equal slices; this launch handles
+    // slices [slice_begin, slice_begin + gridDim.y) (blockIdx.y picks one).  Slices of one launch
+    // fill the GPU when there are few groups; slices of different launches are the shares of a
+    // multi-GPU run.  Slice 0 also does the group's own tiles.
+    int slice_begin;
+    int n_slices;
     double* ax; double* ay; double* az;   // length n, original order, accumulated atomically
     const int* uniform_mass;
     const double* common_gm;
@@ -150,10 +154,11 @@ __device__ __forceinline__ void visit_dispatch(int kind, const PairConsts& k, do
 template <int I, bool SOFT0>
 __global__ void __launch_bounds__(WG, 4) k_pairs_sym(const SymArgs a) {
     const int lane = threadIdx.x & 63;
-    const int group = __builtin_amdgcn_readfirstlane(a.group_begin + blockIdx.x * (WG / 64) + (threadIdx.x >> 6));
-    if (group >= a.group_end) return;   // whole wavefronts leave together; nothing is shared
     const PairConsts k = a.k;
     const int T = a.n_tiles, NG = T / I;
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * (WG / 64) + (threadIdx.x >> 6));
+    if (group >= NG) return;   // whole wavefronts leave together; nothing is shared
+    const int slice = a.slice_begin + blockIdx.y;
     const bool uniform = __builtin_amdgcn_readfirstlane(a.uniform_mass[0]) != 0;
 
     double xi[I], yi[I], zi[I], wi[I], ax[I], ay[I], az[I];
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(WG, 4) k_pairs_sym(const SymArgs a) {
 
     // ---- the group against its own tiles: ordered pairs, no reaction ----
 #pragma unroll 1
-    for (int u2 = 0; u2 < I; ++u2) {
+    for (int u2 = 0; u2 < (slice == 0 ? I : 0); ++u2) {
         const int p = (group * I + u2) * 64 + lane;
         double rx = 0, ry = 0, rz = 0;
         // a group is compact, but a tiny box can still put members half a box apart: wrap per pair
@@ -187,10 +192,13 @@ __global__ void __launch_bounds__(WG, 4) k_pairs_sym(const SymArgs a) {
     // ---- the next half of all groups, circularly ----
     const int half_groups = (NG - 1) / 2;
     const int n_groups = half_groups + ((NG % 2 == 0 && group < NG / 2) ? 1 : 0);
-    int b = ((group + 1) % NG) * I;
+    const long long n_visits_all = static_cast<long long>(n_groups) * I;
+    const int visit_begin = static_cast<int>(n_visits_all * slice / a.n_slices);
+    const int visit_end = static_cast<int>(n_visits_all * (slice + 1) / a.n_slices);
+    int b = static_cast<int>((static_cast<long long>((group + 1) % NG) * I + visit_begin) % T);
     const double scale = uniform ? a.common_gm[0] : 1.0;
 #pragma unroll 1
-    for (int visit = 0; visit < n_groups * I; ++visit) {
+    for (int visit = visit_begin; visit < visit_end; ++visit) {
         const int p = b * 64 + lane;
         double xj = a.sx[p], yj = a.sy[p], zj = a.sz[p], wj = a.sgm[p];
         double rx = 0.0, ry = 0.0, rz = 0.0;
