@@ -485,3 +485,53 @@ def test_default_ini_total_acceleration_matches_reference_output(lib, oracle):
         assert acc[c][0] == pytest.approx(kat["p0_acc_initial_pm_plus_pp"][c], rel=1e-12)
     assert float(np.max(acc[0] ** 2 + acc[1] ** 2 + acc[2] ** 2)) == \
         pytest.approx(kat["max_accel_sq"], rel=1e-12)
+
+
+# --------------------------------------------------------------------------------------
+# stress: separations at and around half a box, extreme clustering
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("variant", [0, ffi.KERNEL_DIRECT, ffi.KERNEL_DIRECT_SYMMETRIC])
+def test_half_box_separated_clusters(lib, oracle, seed, variant):
+    """Tight clusters whose mutual separations sit at L/2 +- a few cluster radii on random axes,
+    in boxes of assorted lengths: every tile pair is a uniform-shift, straddle or generic case
+    decided by a few ulps of the bounding boxes."""
+    rng = np.random.default_rng(100 + seed)
+    L = [1.0, 2.0, 0.75, 10.0, 64.0, 3.3][seed]
+    n_clusters, per = 6, 700
+    centres = rng.random((n_clusters, 3)) * L
+    for c in range(1, n_clusters):       # place each centre half a box from the previous one
+        axes = rng.random(3) < 0.6
+        centres[c] = np.where(axes, centres[c - 1] + 0.5 * L + rng.normal(0, 2e-3 * L, 3), centres[c])
+    pts = (centres[:, None, :] + rng.normal(0, 1.5e-3 * L, (n_clusters, per, 3))).reshape(-1, 3)
+    pts[:50] = np.round(pts[:50] / (L / 64)) * (L / 64)      # some exactly on a 1/64 lattice
+    pts = np.mod(pts, L)
+    pos = [np.ascontiguousarray(pts[:, c]) for c in range(3)]
+    n = pts.shape[0]
+    m = datasets.masses(n, equal=bool(seed % 2))
+    p = Config(DOMAIN_SIZE=L, MESH_SIZE=16, N_PER_SIDE=16, USE_PM=False).pp_params()
+    want = oracle.accumulate(p, *pos, m)
+    lib.set_option(ffi.OPT_FORCE_KERNEL, variant)
+    try:
+        got = gpu_acc(lib, p, pos, m)
+    finally:
+        lib.set_option(ffi.OPT_FORCE_KERNEL, 0)
+    assert normalised_error(got, want) < TOL
+
+
+def test_p3m_extreme_clustering(lib, oracle):
+    """Thousands of particles inside one search cell (late-time haloes): long runs, queue drains
+    in the middle of a run, heavy per-cell ordering."""
+    rng = np.random.default_rng(5)
+    blob = 0.37 + 2e-3 * rng.random((3000, 3))
+    edge = np.mod(0.999 + 4e-3 * rng.random((1500, 3)), 1.0)     # a halo across the box corner
+    bg = rng.random((6000, 3))
+    pts = np.concatenate([blob, edge, bg])
+    pos = [np.ascontiguousarray(pts[:, c]) for c in range(3)]
+    m = datasets.masses(pts.shape[0], equal=False)
+    p = Config(MESH_SIZE=32, N_PER_SIDE=22, USE_PM=True).pp_params()
+    want = oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS)
+    got = gpu_acc(lib, p, pos, m)
+    assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
+    assert normalised_error(got, want) < TOL
+    assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
