@@ -44,10 +44,14 @@ def cpu_baseline(p, pos, m, mode, budget_s=15.0):
         pairs = n_tgt * (n - 1)
         sample = f"{n_tgt} targets x all {n} sources, {dt:.2f} s"
     else:
-        n_tgt = min(n, 32768 * cores // 4)
-        t0 = time.perf_counter()
-        orc.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=EXACT_CELLS, nthreads=cores)
-        dt = time.perf_counter() - t0
+        n_tgt = min(n, 8192 * cores)
+        while True:
+            t0 = time.perf_counter()
+            orc.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=EXACT_CELLS, nthreads=cores)
+            dt = time.perf_counter() - t0
+            if dt > 0.25 * budget_s or n_tgt == n:
+                break
+            n_tgt = min(n, int(n_tgt * max(2.0, 0.6 * budget_s / max(dt, 1e-3))))
         pairs = orc.count_within_cutoff(p, *pos, tgt_begin=0, n_tgt=n_tgt, nthreads=cores)
         sample = f"{n_tgt} targets, cell search over the reference's mesh cells, {dt:.2f} s"
     return {"value": pairs / dt / 1e9, "unit": "Ginter/s", "cores": cores, "kind": "port",
