@@ -151,6 +151,8 @@ __device__ __forceinline__ void visit_dispatch(int kind, const PairConsts& k, do
     }
 }
 
+constexpr int HOME_FLUSH = 64;   // visits between two flushes of a group's own sums (power of 2)
+
 template <int I, bool SOFT0>
 __global__ void __launch_bounds__(WG, 4) k_pairs_sym(const SymArgs a) {
     const int lane = threadIdx.x & 63;
@@ -242,6 +244,23 @@ __global__ void __launch_bounds__(WG, 4) k_pairs_sym(const SymArgs a) {
             unsafeAtomicAdd(&a.az[o], rz * scale);
         }
         if (++b == T) b = 0;
+        // The group's own sums go out every HOME_FLUSH visits, not once at the end: a register
+        // sum that runs over millions of terms rounds at the magnitude of its largest partial
+        // sum (the pull of half the box) every time, and short chains keep that error an order
+        // of magnitude below that of one long sequential sum, for 3*I atomics per 64 visits.
+        if (((visit - visit_begin) & (HOME_FLUSH - 1)) == HOME_FLUSH - 1) {
+#pragma unroll
+            for (int u = 0; u < I; ++u) {
+                const int ph = (group * I + u) * 64 + lane;
+                if (ph < a.n) {
+                    const int o = a.order[ph];
+                    unsafeAtomicAdd(&a.ax[o], ax[u] * scale);
+                    unsafeAtomicAdd(&a.ay[o], ay[u] * scale);
+                    unsafeAtomicAdd(&a.az[o], az[u] * scale);
+                }
+                ax[u] = 0.0; ay[u] = 0.0; az[u] = 0.0;
+            }
+        }
     }
 
 #pragma unroll
