@@ -350,6 +350,21 @@ bool p3m_search_grid(const nbpp_params* p, int* radius, int* nside) {
     return true;
 }
 
+// Single-precision r^2 bound of the cutoff pre-filter.  Stored coordinates lie in
+// [0, X], X = L (1 + (R+1)/nside), so rounding one to fp32 moves it by at most 2^-24 X; a
+// displacement component of a pair inside the cutoff is therefore off by at most
+// e = 2^-23 X + 2^-23 rc (two roundings plus the subtraction's own), and the fp32 sum of
+// squares, three roundings deep, by a factor below 1 + 2^-22.  Hence for r <= rc
+//   r2_fp32 <= (rc^2 + 2 sqrt(3) e rc + 3 e^2) (1 + 2^-22);
+// the bound below adds slack and rounds up.  Candidates it lets through are re-tested in fp64.
+float p3m_prefilter_bound(const nbpp_params* p, const GhostGrid& grid) {
+    const double rc = std::sqrt(p->cutoff_sq);
+    const double X = p->domain_size * (1.0 + (grid.R + 1.0) / grid.nside);
+    const double e = std::ldexp(X, -23) + std::ldexp(rc, -23);
+    const double bound = (rc * rc + 2.0 * std::sqrt(3.0) * e * rc + 3.0 * e * e) * (1.0 + std::ldexp(1.0, -20));
+    return std::nextafter(static_cast<float>(bound), INFINITY);
+}
+
 int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double* y,
                   const double* z, const double* m, int tgt_begin, int n_tgt, double* ax,
                   double* ay, double* az, hipStream_t s) {
@@ -389,13 +404,15 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     CHK(g.src.x.ensure(sizeof(double4) * n_entries));  // AoS records live in the x buffer
     int* entries = g.src.order.as<int>();
     double4* rec = g.src.x.as<double4>();
+    CHK(g.src.y.ensure(sizeof(float4) * n_entries));   // and their fp32 copies in the y buffer
+    float4* frec = g.src.y.as<float4>();
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
     hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
                        start, count, entries);
     hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s, static_cast<int>(ncell),
                        start, entries);
     hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries,
-                       cx, cy, cz, m, p->G, p->domain_size, rec);
+                       cx, cy, cz, m, p->G, p->domain_size, rec, frec);
 
     // 3. compact list of targets in sorted order
     CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));
@@ -416,15 +433,21 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
 
     // 4. pairs
     P3MArgs a{};
-    a.rec = rec; a.entries = entries; a.cell_start = start; a.tlist = tlist;
+    a.rec = rec; a.frec = frec; a.prefilter_sq = p3m_prefilter_bound(p, grid);
+    a.entries = entries; a.cell_start = start; a.tlist = tlist;
     a.n_entries = n_entries; a.n_tgt = n_tgt; a.tgt_begin = tgt_begin; a.g = grid;
     a.ax = ax; a.ay = ay; a.az = az;
     a.accepted = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
     a.k = k;
-    if (p->soft_sq == 0.0)
-        hipLaunchKernelGGL(k_p3m_cells<true>, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_p3m_cells<false>, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, a);
+    const bool wide = n_entries >= (1 << 27);   // 32-byte records beyond 32-bit byte offsets
+    const dim3 grid_dim(cdiv(n_tgt, WG)), wg_dim(WG);
+    if (p->soft_sq == 0.0) {
+        if (wide) hipLaunchKernelGGL((k_p3m_cells<true, true>), grid_dim, wg_dim, 0, s, a);
+        else      hipLaunchKernelGGL((k_p3m_cells<true, false>), grid_dim, wg_dim, 0, s, a);
+    } else {
+        if (wide) hipLaunchKernelGGL((k_p3m_cells<false, true>), grid_dim, wg_dim, 0, s, a);
+        else      hipLaunchKernelGGL((k_p3m_cells<false, false>), grid_dim, wg_dim, 0, s, a);
+    }
     HIPCHK(hipGetLastError());
     g.stats.pairs_evaluated = 0;  // candidates depend on the data; see pairs_accepted
     g.stats.pair_launches = 1;

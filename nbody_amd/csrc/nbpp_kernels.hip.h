@@ -711,14 +711,18 @@ __device__ __forceinline__ double image_shift(unsigned code2, double L) {
 __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
                                const double* __restrict__ x, const double* __restrict__ y,
                                const double* __restrict__ z, const double* __restrict__ m,
-                               double G, double L, double4* __restrict__ rec) {
+                               double G, double L, double4* __restrict__ rec,
+                               float4* __restrict__ frec) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_entries) return;
     const unsigned e = static_cast<unsigned>(entries[p]);
     const int i = static_cast<int>(e & GHOST_INDEX_MASK);
     const unsigned code = e >> GHOST_SHIFT;
-    rec[p] = make_double4(x[i] + image_shift(code & 3u, L), y[i] + image_shift((code >> 2) & 3u, L),
-                          z[i] + image_shift((code >> 4) & 3u, L), G * m[i]);
+    const double4 r = make_double4(x[i] + image_shift(code & 3u, L), y[i] + image_shift((code >> 2) & 3u, L),
+                                   z[i] + image_shift((code >> 4) & 3u, L), G * m[i]);
+    rec[p] = r;
+    // single-precision copy for the cutoff pre-filter of k_p3m_cells
+    frec[p] = make_float4(static_cast<float>(r.x), static_cast<float>(r.y), static_cast<float>(r.z), 0.0f);
 }
 
 // Targets = real (code 0) entries whose original index lies in [tgt_begin, tgt_begin+n_tgt).
@@ -770,6 +774,8 @@ __device__ __forceinline__ void p3m_accepted(double dx, double dy, double dz, do
 
 struct P3MArgs {
     const double4* rec;      // sorted records incl. ghosts: {x, y, z, G*m}
+    const float4* frec;      // the same positions rounded to fp32 (pre-filter)
+    float prefilter_sq;      // fp32 r^2 bound that no pair with r^2 <= cutoff_sq can exceed
     const int* entries;      // original index | image code << 26
     const int* cell_start;   // [np^3 + 1]
     const int* tlist;        // sorted positions of the targets
@@ -782,77 +788,175 @@ struct P3MArgs {
     PairConsts k;
 };
 
-constexpr int P3M_QCAP = 24;   // accepted-pair queue entries per lane (24 KiB LDS per workgroup)
+constexpr int P3M_QCAP = 16;    // accepted-pair ring per lane (power of 2; 16 KiB LDS per workgroup)
+constexpr int P3M_DRAIN_UNROLL = 2;   // record fetches in flight per lane while draining
+constexpr int P3M_DRAIN = 8;   // entries every lane evaluates when some lane's ring is full
 
 // One lane per target.  Two phases per lane, interleaved wave-wide:
-//   filter: walk the (2R+1)^2 runs, form r^2 for every candidate, push the sorted position of
-//           the ones inside the cutoff onto the lane's queue in LDS (cheap, ~25 % pass);
-//   drain:  when any lane's queue is full (and at the end), every lane evaluates its queued
-//           pairs with the full taper / double-softening arithmetic (dense: lanes hold similar
-//           numbers of entries).
+//   filter: walk the (2R+1)^2 runs, two candidates per trip, and push the sorted position of
+//           every candidate that may lie inside the cutoff onto the lane's ring in LDS (~30 %
+//           pass).  The test runs in single precision on 16-byte records against a bound that
+//           no pair inside the cutoff can exceed (P3MArgs::prefilter_sq): per candidate the
+//           vector cache returns 16 bytes per lane instead of 24, and the loop is bound by that
+//           return path as much as by instruction issue.
+//   drain:  when any lane's ring is full every lane evaluates its P3M_DRAIN oldest entries from
+//           the fp64 records: exact r^2, the reference's cutoff test (src/particles.cpp:326),
+//           then the full taper / double-softening arithmetic.  What a lane does not evaluate
+//           now stays queued; the rest is done at the end.
 // Without the queue every candidate iteration in which ANY lane passes the cutoff pays for the
 // full pair function on all 64 lanes.
-template <bool SOFT0>
+//
+// WIDE = false addresses records with 32-bit byte offsets (n_entries < 2^27).
+template <bool WIDE>
+__device__ __forceinline__ double4 load_record(const double4* rec, int idx) {
+    if constexpr (WIDE) return rec[idx];
+    return *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(rec) +
+                                             (static_cast<uint32_t>(idx) << 5));
+}
+template <bool WIDE>
+__device__ __forceinline__ float4 load_frecord(const float4* rec, int idx) {
+    if constexpr (WIDE) return rec[idx];
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(rec) +
+                                            (static_cast<uint32_t>(idx) << 4));
+}
+__device__ __forceinline__ int load_word(const int* base, int idx) {   // idx < 2^30
+    return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) +
+                                         (static_cast<uint32_t>(idx) << 2));
+}
+static_assert((P3M_QCAP & (P3M_QCAP - 1)) == 0 && P3M_DRAIN % P3M_DRAIN_UNROLL == 0 &&
+              P3M_QCAP % P3M_DRAIN_UNROLL == 0, "ring sizes");
+__device__ __forceinline__ int ring_slot(int i) { return i & (P3M_QCAP - 1); }
+
+// 16-byte load that fetches nothing and returns zeros for lanes whose byte offset is past the
+// end of the buffer (hardware range check): masking a lane costs one select, no branch.
+__device__ __forceinline__ float4 load_frecord_checked(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 0);
+    const v4f f = __builtin_bit_cast(v4f, w);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
+__device__ __forceinline__ double4 load_record_checked(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d lo = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 0));
+    const v2d hi = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset + 16u, 0, 0));
+    return make_double4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <bool SOFT0, bool WIDE>
 __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
     __shared__ int queue[P3M_QCAP][WG];
     const int t = blockIdx.x * WG + threadIdx.x;
     const bool live = t < a.n_tgt;
     const int p = a.tlist[live ? t : a.n_tgt - 1];
     const double4 me = a.rec[p];
+    const float4 mef = a.frec[p];
     const GhostGrid g = a.g;
     const PairConsts k = a.k;
+    const float bound = a.prefilter_sq;
     const int pcx = bin_coord(me.x, g.scale, g.nside) + g.R;
     const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
     const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
     double ax = 0.0, ay = 0.0, az = 0.0;
-    int cnt = 0;
+    int head = 0, cnt = 0;
     unsigned hits = 0;
+    // WIDE: more than 2^31 bytes of filter records; the range check then covers the first 2^31
+    // only and lanes are masked by pointing them at their own record instead
+    const uint32_t frec_bytes = WIDE ? 0x7ffffff0u : static_cast<uint32_t>(a.n_entries) << 4;
+    const __amdgpu_buffer_rsrc_t frec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.frec), 0, frec_bytes, 0x00020000);
 
-    auto drain = [&]() {
-        int most = cnt;
+    // evaluates up to `quota` (a multiple of DU) of the oldest queued candidates of every lane,
+    // DU at a time so that DU record fetches are in flight together: the loop is a chain of
+    // LDS read -> record fetch -> arithmetic, and the fetch latency is most of its cost
+    constexpr int DU = P3M_DRAIN_UNROLL;
+    const uint32_t rec_bytes = WIDE ? 0xffffffe0u : static_cast<uint32_t>(a.n_entries) << 5;
+    const __amdgpu_buffer_rsrc_t rec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
+    auto drain = [&](int quota) {
+#pragma unroll 1
+        for (int q = 0; q < quota && __any(q < cnt); q += DU) {
+            double4 s[DU];
+            bool valid[DU];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) most = max(most, __shfl_xor(most, d, 64));
-        for (int q = 0; q < most; ++q) {
-            if (q < cnt) {
-                const double4 s = a.rec[queue[q][threadIdx.x]];
-                const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+            for (int u = 0; u < DU; ++u) {
+                const int idx = queue[q + u < cnt ? ring_slot(head + q + u) : 0][threadIdx.x];
+                valid[u] = q + u < cnt && idx != p;   // the target itself passes the pre-filter
+                if constexpr (WIDE) s[u] = a.rec[valid[u] ? idx : p];
+                else s[u] = load_record_checked(rec_rsrc, valid[u] ? static_cast<uint32_t>(idx) << 5 : 0xffffffe0u);
+            }
+#pragma unroll
+            for (int u = 0; u < DU; ++u) {
+                const double dx = s[u].x - me.x, dy = s[u].y - me.y, dz = s[u].z - me.z;
                 const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-                p3m_accepted<SOFT0>(dx, dy, dz, r2, s.w, k, ax, ay, az);
+                if (valid[u] && !(r2 > k.cutoff_sq)) {
+                    p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, ax, ay, az);
+                    ++hits;
+                }
             }
         }
-        hits += cnt;
-        cnt = 0;
+        const int taken = min(quota, cnt);
+        head = ring_slot(head + taken);
+        cnt -= taken;
     };
 
-    // Filter phase.  Lanes of a wavefront are neighbours along x, so their loads of the same
-    // run hit the same cache lines.  (Staging the union of the runs through LDS was measured
-    // slower: the loop is bound by instruction issue, not by the vector cache.)
+    // Rows (ox, oy) in [-R, R]^2, oy fastest; the wavefront walks them together.  `base` is the
+    // padded id of the middle cell of the row whose bounds are in flight into (nj, nje): they
+    // are requested when the row before is entered.
     const int span = 2 * g.R + 1;
-    for (int row = 0; row < span * span; ++row) {
-        const int ox = row / span - g.R, oy = row % span - g.R;
-        const int base = ((pcx + ox) * g.np + (pcy + oy)) * g.np + pcz;
-        int j = live ? a.cell_start[base - g.R] : 0;
-        const int je = live ? a.cell_start[base + g.R + 1] : 0;
-        while (__any(j < je)) {   // two candidates per lane per trip: half the loop overhead
+    const int n_rows = span * span;
+    const int row_jump = g.np * (g.np - span + 1);   // last row of one ox to the first of the next
+    int base = ((pcx - g.R) * g.np + (pcy - g.R)) * g.np + pcz;
+    int row = 0, oy = 0;   // rows entered so far; wave-uniform
+    int j = 0, je = 0;
+    int nj = load_word(a.cell_start, base - g.R), nje = load_word(a.cell_start, base + g.R + 1);
+    bool done = false;
+#pragma unroll 1
+    while (!done) {
+        // ---- filter until some lane's ring is full or the rows are used up.  This loop does
+        // not touch the sums, so they stay in their registers across it.
+#pragma unroll 1
+        for (;;) {
+            if (!__any(j < je)) {   // every lane has finished its run: enter the next row
+                if (row == n_rows) { done = true; break; }
+                j = nj; je = nje;
+                ++row;
+                const bool wrap = oy + 1 == span;
+                base += (row < n_rows) ? (wrap ? row_jump : g.np) : 0;   // after the last row: itself again
+                oy = wrap ? 0 : oy + 1;
+                nj = load_word(a.cell_start, base - g.R);
+                nje = load_word(a.cell_start, base + g.R + 1);
+            }
+            // two candidates per lane per trip; an exhausted lane fetches nothing and is rejected
             const bool v0 = j < je, v1 = j + 1 < je;
-            double4 s0 = me, s1 = me;
-            if (v0) s0 = a.rec[j];
-            if (v1) s1 = a.rec[j + 1];
+            float4 f0, f1;
+            if constexpr (WIDE) {
+                f0 = a.frec[v0 ? j : p];
+                f1 = a.frec[v1 ? j + 1 : p];
+            } else {
+                const uint32_t off = static_cast<uint32_t>(j) << 4;
+                f0 = load_frecord_checked(frec_rsrc, v0 ? off : 0xfffffff0u);
+                f1 = load_frecord_checked(frec_rsrc, v1 ? off + 16u : 0xfffffff0u);
+            }
+            // the slot after the newest entry is free (cnt <= QCAP-2 here): the stores need no branch
             {
-                const double dx = s0.x - me.x, dy = s0.y - me.y, dz = s0.z - me.z;
-                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-                if (v0 && !(r2 > k.cutoff_sq) && j != p) queue[cnt++][threadIdx.x] = j;
+                const float dx = f0.x - mef.x, dy = f0.y - mef.y, dz = f0.z - mef.z;
+                const float r2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+                queue[ring_slot(head + cnt)][threadIdx.x] = j;
+                cnt += (v0 & !(r2 > bound)) ? 1 : 0;
             }
             {
-                const double dx = s1.x - me.x, dy = s1.y - me.y, dz = s1.z - me.z;
-                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-                if (v1 && !(r2 > k.cutoff_sq) && j + 1 != p) queue[cnt++][threadIdx.x] = j + 1;
+                const float dx = f1.x - mef.x, dy = f1.y - mef.y, dz = f1.z - mef.z;
+                const float r2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+                queue[ring_slot(head + cnt)][threadIdx.x] = j + 1;
+                cnt += (v1 & !(r2 > bound)) ? 1 : 0;
             }
             j += 2;
-            if (__any(cnt >= P3M_QCAP - 1)) drain();
+            if (__any(cnt >= P3M_QCAP - 1)) break;
         }
+        drain(done ? P3M_QCAP : P3M_DRAIN);
     }
-    drain();
 
     if (live) {
         const int o = static_cast<int>(static_cast<unsigned>(a.entries[p]) & GHOST_INDEX_MASK) - a.tgt_begin;

@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libnbpp.so")
+# NBPP_LIB points at another build of the library (kernel experiments)
+LIB_PATH = os.environ.get("NBPP_LIB") or os.path.join(HERE, "lib", "libnbpp.so")
 
 KERNEL_NONE, KERNEL_DIRECT, KERNEL_DIRECT_WRAP, KERNEL_P3M_CELLS, KERNEL_P3M_ALLPAIRS, \
     KERNEL_DIRECT_SYMMETRIC = range(6)
