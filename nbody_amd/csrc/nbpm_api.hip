@@ -1,0 +1,446 @@
+// nbpm_api.hip - libnbpm.so: the mesh (long-range) side of the gravity step on gfx950.
+//
+// Pipeline of one call (all HBM-bandwidth-bound; meshes are N^3 fp64, z fastest):
+//   k_cic_deposit      particles -> rho          8 fp64 atomics per particle (L2 atomics)
+//   hipFFT D2Z         rho -> rho_k              N x N x (N/2+1) complex
+//   k_greens           phi_k = -4 pi G rho_k/k^2 in place
+//   hipFFT Z2D         phi_k -> phi              unnormalised, like the reference's c2r
+//   k_gradient         phi -> gx, gy, gz         central differences, periodic
+//   k_cic_interpolate  meshes -> acc             8 gathers per mesh per particle
+// Each statement follows the reference's operation order so that everything but the two FFTs
+// and the order of the deposit's additions is bit for bit the reference's arithmetic
+// (compiled with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/nbpm.h"
+
+namespace {
+
+constexpr int WG = 256;
+constexpr double PI = 3.14159265358979323846;   // M_PI
+
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(NBPM_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define FFTCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipfftResult r_ = (expr);                                                             \
+        if (r_ != HIPFFT_SUCCESS)                                                             \
+            return fail(NBPM_ERR_HIP, "%s: hipfftResult %d (%s:%d)", #expr, (int)r_, __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != NBPM_OK) return rc_; \
+    } while (0)
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return NBPM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(NBPM_ERR_NOMEM, "hipMalloc of %zu bytes failed", bytes);
+        }
+        cap = bytes;
+        return NBPM_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipfftHandle r2c = 0, c2r = 0;
+    int plan_n = 0;
+    Buf spectrum, phi;                 // rho_k / phi_k (complex), phi (real)
+    Buf rho, grav[3];                  // library-owned meshes of nbpm_accelerations_device
+    Buf host_in[4], host_acc[3];
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing = false;
+    nbpm_stats stats{};
+};
+Ctx g;
+std::mutex g_mu;
+
+inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
+
+// ---- cloud-in-cell geometry of one particle: src/particles.cpp:60-83 / :112-114 ----
+struct Cloud {
+    int i0[3], i1[3];
+    double f[3];
+};
+__device__ __forceinline__ Cloud cloud_of(double px, double py, double pz, double cell, int N) {
+    Cloud c;
+    const double s[3] = {px / cell, py / cell, pz / cell};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int i = static_cast<int>(s[a]);          // :60-62 (truncation)
+        c.f[a] = s[a] - i;                             // :64-66
+        c.i0[a] = (i + N) % N;                         // :81-83
+        c.i1[a] = (i + 1 + N) % N;
+    }
+    return c;
+}
+// w000, w100, w010, w110, w001, w101, w011, w111 with the reference's grouping (:69-76)
+__device__ __forceinline__ void cloud_weights(const Cloud& c, double (&w)[8]) {
+    const double fx = c.f[0], fy = c.f[1], fz = c.f[2];
+    w[0] = (1 - fx) * (1 - fy) * (1 - fz);
+    w[1] = fx * (1 - fy) * (1 - fz);
+    w[2] = (1 - fx) * fy * (1 - fz);
+    w[3] = fx * fy * (1 - fz);
+    w[4] = (1 - fx) * (1 - fy) * fz;
+    w[5] = fx * (1 - fy) * fz;
+    w[6] = (1 - fx) * fy * fz;
+    w[7] = fx * fy * fz;
+}
+__device__ __forceinline__ size_t corner(const Cloud& c, int q, int N) {   // q = cx + 2 cy + 4 cz
+    const int ix = (q & 1) ? c.i1[0] : c.i0[0];
+    const int iy = (q & 2) ? c.i1[1] : c.i0[1];
+    const int iz = (q & 4) ? c.i1[2] : c.i0[2];
+    return (static_cast<size_t>(ix) * N + iy) * N + iz;
+}
+
+// rho += m * w / V.  The reference sums m * w and divides the finished mesh by the cell volume
+// (:85-92, :99); here every term is divided, which is the same to rounding and saves a pass.
+__global__ void __launch_bounds__(WG) k_cic_deposit(size_t n, const double* __restrict__ x,
+                                                    const double* __restrict__ y,
+                                                    const double* __restrict__ z,
+                                                    const double* __restrict__ m, double cell,
+                                                    double cell_volume, int N, double* __restrict__ rho) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    if (i >= n) return;
+    const Cloud c = cloud_of(x[i], y[i], z[i], cell, N);
+    double w[8];
+    cloud_weights(c, w);
+    const double mi = m[i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) unsafeAtomicAdd(&rho[corner(c, q, N)], (mi * w[q]) / cell_volume);
+}
+
+// phi_k = rho_k * (-4 pi G / k^2), phi_0 = 0                      src/integrator.cpp:78-103
+__global__ void __launch_bounds__(WG) k_greens(int N, double L, double G, double2* __restrict__ spec) {
+    const int nk = N / 2 + 1;
+    const size_t total = static_cast<size_t>(N) * N * nk;
+    const size_t idx = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    if (idx >= total) return;
+    const int k = static_cast<int>(idx % nk);
+    const int j = static_cast<int>((idx / nk) % N);
+    const int i = static_cast<int>(idx / (static_cast<size_t>(nk) * N));
+    if (i == 0 && j == 0 && k == 0) {
+        spec[0] = make_double2(0.0, 0.0);
+        return;
+    }
+    const double kx_freq = static_cast<double>((i < N / 2) ? i : (i - N));
+    const double ky_freq = static_cast<double>((j < N / 2) ? j : (j - N));
+    const double kz_freq = static_cast<double>(k);
+    const double kx = kx_freq * 2.0 * PI / L;
+    const double ky = ky_freq * 2.0 * PI / L;
+    const double kz = kz_freq * 2.0 * PI / L;
+    const double k2 = kx * kx + ky * ky + kz * kz;
+    const double f = -4.0 * PI * G / k2;
+    const double2 v = spec[idx];
+    spec[idx] = make_double2(v.x * f, v.y * f);
+}
+
+// g = (phi(+1) - phi(-1)) * factor along each axis, periodic            src/integrator.cpp:108-131
+__global__ void __launch_bounds__(WG) k_gradient(int N, double factor, const double* __restrict__ phi,
+                                                 double* __restrict__ gx, double* __restrict__ gy,
+                                                 double* __restrict__ gz) {
+    const size_t total = static_cast<size_t>(N) * N * N;
+    const size_t idx = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    if (idx >= total) return;
+    const int k = static_cast<int>(idx % N);
+    const int j = static_cast<int>((idx / N) % N);
+    const int i = static_cast<int>(idx / (static_cast<size_t>(N) * N));
+    const int ip1 = (i + 1 == N) ? 0 : i + 1, im1 = (i == 0) ? N - 1 : i - 1;
+    const int jp1 = (j + 1 == N) ? 0 : j + 1, jm1 = (j == 0) ? N - 1 : j - 1;
+    const int kp1 = (k + 1 == N) ? 0 : k + 1, km1 = (k == 0) ? N - 1 : k - 1;
+    auto at = [&](int a, int b, int c) { return phi[(static_cast<size_t>(a) * N + b) * N + c]; };
+    gx[idx] = (at(ip1, j, k) - at(im1, j, k)) * factor;
+    gy[idx] = (at(i, jp1, k) - at(i, jm1, k)) * factor;
+    gz[idx] = (at(i, j, kp1) - at(i, j, km1)) * factor;
+}
+
+// acc = sum of the 8 corner values * weights, in the reference's order   src/particles.cpp:116-129
+__global__ void __launch_bounds__(WG) k_cic_interpolate(size_t n, const double* __restrict__ x,
+                                                        const double* __restrict__ y,
+                                                        const double* __restrict__ z, double cell, int N,
+                                                        const double* __restrict__ gx,
+                                                        const double* __restrict__ gy,
+                                                        const double* __restrict__ gz,
+                                                        double* __restrict__ ax, double* __restrict__ ay,
+                                                        double* __restrict__ az) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    if (i >= n) return;
+    const Cloud c = cloud_of(x[i], y[i], z[i], cell, N);
+    double w[8];
+    cloud_weights(c, w);
+    size_t at[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) at[q] = corner(c, q, N);
+    auto interp = [&](const double* __restrict__ grid) {
+        double s = grid[at[0]] * w[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s = s + grid[at[q]] * w[q];
+        return s;
+    };
+    ax[i] = interp(gx);
+    ay[i] = interp(gy);
+    az[i] = interp(gz);
+}
+
+int check_params(const nbpm_params* p) {
+    if (!p) return fail(NBPM_ERR_ARG, "params is NULL");
+    if (!(p->domain_size > 0.0) || !std::isfinite(p->domain_size))
+        return fail(NBPM_ERR_ARG, "domain_size must be positive and finite");
+    if (!std::isfinite(p->G)) return fail(NBPM_ERR_ARG, "G must be finite");
+    if (p->mesh_size < 2 || p->mesh_size > 1290)
+        return fail(NBPM_ERR_ARG, "mesh_size must be in [2, 1290] (got %d)", p->mesh_size);
+    return NBPM_OK;
+}
+
+int ensure_plans(int N, hipStream_t s) {
+    if (g.plan_n != N) {
+        if (g.plan_n) {
+            (void)hipfftDestroy(g.r2c);
+            (void)hipfftDestroy(g.c2r);
+            g.plan_n = 0;
+        }
+        FFTCHK(hipfftPlan3d(&g.r2c, N, N, N, HIPFFT_D2Z));
+        if (hipfftPlan3d(&g.c2r, N, N, N, HIPFFT_Z2D) != HIPFFT_SUCCESS) {
+            (void)hipfftDestroy(g.r2c);
+            return fail(NBPM_ERR_HIP, "hipfftPlan3d(Z2D, %d^3) failed", N);
+        }
+        g.plan_n = N;
+    }
+    FFTCHK(hipfftSetStream(g.r2c, s));
+    FFTCHK(hipfftSetStream(g.c2r, s));
+    return NBPM_OK;
+}
+
+int deposit(const nbpm_params* p, size_t n, const double* x, const double* y, const double* z,
+            const double* m, double* rho, hipStream_t s) {
+    const int N = p->mesh_size;
+    const size_t cells = static_cast<size_t>(N) * N * N;
+    const double cell = p->domain_size / N;              // CELL_SIZE   (src/config.cpp:74)
+    const double volume = cell * cell * cell;            // CELL_VOLUME (src/config.cpp:75)
+    HIPCHK(hipMemsetAsync(rho, 0, sizeof(double) * cells, s));
+    if (n) {
+        hipLaunchKernelGGL(k_cic_deposit, dim3(cdiv(n, WG)), dim3(WG), 0, s, n, x, y, z, m, cell, volume, N, rho);
+        HIPCHK(hipGetLastError());
+    }
+    return NBPM_OK;
+}
+
+int solve(const nbpm_params* p, const double* rho, double* gx, double* gy, double* gz, hipStream_t s) {
+    const int N = p->mesh_size;
+    const size_t cells = static_cast<size_t>(N) * N * N;
+    const size_t modes = static_cast<size_t>(N) * N * (N / 2 + 1);
+    CHK(ensure_plans(N, s));
+    CHK(g.spectrum.ensure(sizeof(double2) * modes));
+    CHK(g.phi.ensure(sizeof(double) * cells));
+    double2* spec = g.spectrum.as<double2>();
+    double* phi = g.phi.as<double>();
+    // out-of-place, so the caller's density survives
+    FFTCHK(hipfftExecD2Z(g.r2c, const_cast<double*>(rho), reinterpret_cast<hipfftDoubleComplex*>(spec)));
+    hipLaunchKernelGGL(k_greens, dim3(cdiv(modes, WG)), dim3(WG), 0, s, N, p->domain_size, p->G, spec);
+    HIPCHK(hipGetLastError());
+    FFTCHK(hipfftExecZ2D(g.c2r, reinterpret_cast<hipfftDoubleComplex*>(spec), phi));
+    const double cell = p->domain_size / N;
+    const double norm = 1.0 / (static_cast<double>(N) * N * N);   // src/integrator.cpp:108
+    const double factor = -norm / (2.0 * cell);                   // :109
+    hipLaunchKernelGGL(k_gradient, dim3(cdiv(cells, WG)), dim3(WG), 0, s, N, factor, phi, gx, gy, gz);
+    HIPCHK(hipGetLastError());
+    return NBPM_OK;
+}
+
+int interpolate(const nbpm_params* p, size_t n, const double* x, const double* y, const double* z,
+                const double* gx, const double* gy, const double* gz, double* ax, double* ay,
+                double* az, hipStream_t s) {
+    if (!n) return NBPM_OK;
+    const int N = p->mesh_size;
+    const double cell = p->domain_size / N;
+    hipLaunchKernelGGL(k_cic_interpolate, dim3(cdiv(n, WG)), dim3(WG), 0, s, n, x, y, z, cell, N, gx, gy, gz,
+                       ax, ay, az);
+    HIPCHK(hipGetLastError());
+    return NBPM_OK;
+}
+
+int accelerations(const nbpm_params* p, size_t n, const double* x, const double* y, const double* z,
+                  const double* m, double* ax, double* ay, double* az, hipStream_t s) {
+    const size_t cells = static_cast<size_t>(p->mesh_size) * p->mesh_size * p->mesh_size;
+    CHK(g.rho.ensure(sizeof(double) * cells));
+    for (Buf& b : g.grav) CHK(b.ensure(sizeof(double) * cells));
+    if (g.timing) HIPCHK(hipEventRecord(g.ev[0], s));
+    CHK(deposit(p, n, x, y, z, m, g.rho.as<double>(), s));
+    if (g.timing) HIPCHK(hipEventRecord(g.ev[1], s));
+    CHK(solve(p, g.rho.as<double>(), g.grav[0].as<double>(), g.grav[1].as<double>(), g.grav[2].as<double>(), s));
+    if (g.timing) HIPCHK(hipEventRecord(g.ev[2], s));
+    CHK(interpolate(p, n, x, y, z, g.grav[0].as<double>(), g.grav[1].as<double>(), g.grav[2].as<double>(),
+                    ax, ay, az, s));
+    if (g.timing) {
+        HIPCHK(hipEventRecord(g.ev[3], s));
+        HIPCHK(hipEventSynchronize(g.ev[3]));
+        float a = 0, b = 0, c = 0;
+        HIPCHK(hipEventElapsedTime(&a, g.ev[0], g.ev[1]));
+        HIPCHK(hipEventElapsedTime(&b, g.ev[1], g.ev[2]));
+        HIPCHK(hipEventElapsedTime(&c, g.ev[2], g.ev[3]));
+        g.stats.deposit_ms = a;
+        g.stats.solve_ms = b;
+        g.stats.interpolate_ms = c;
+        g.stats.total_ms = a + b + c;
+    }
+    return NBPM_OK;
+}
+
+#define ENTER()                                                              \
+    std::lock_guard<std::mutex> lock_(g_mu);                                 \
+    if (!g.ready) return fail(NBPM_ERR_NOINIT, "nbpm_init has not been called"); \
+    HIPCHK(hipSetDevice(g.device))
+
+}  // namespace
+
+extern "C" {
+
+int nbpm_init(int device) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g.ready) {
+        if (g.device == device) return NBPM_OK;
+        return fail(NBPM_ERR_ARG, "already initialised on device %d", g.device);
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return fail(NBPM_ERR_HIP, "no HIP device is visible; libnbpm has no CPU path");
+    }
+    if (device < 0 || device >= count) return fail(NBPM_ERR_ARG, "device %d out of range [0, %d)", device, count);
+    HIPCHK(hipSetDevice(device));
+    for (hipEvent_t& e : g.ev) HIPCHK(hipEventCreate(&e));
+    g.device = device;
+    g.ready = true;
+    return NBPM_OK;
+}
+
+void nbpm_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g.ready) return;
+    (void)hipSetDevice(g.device);
+    (void)hipDeviceSynchronize();
+    if (g.plan_n) {
+        (void)hipfftDestroy(g.r2c);
+        (void)hipfftDestroy(g.c2r);
+        g.plan_n = 0;
+    }
+    for (Buf* b : {&g.spectrum, &g.phi, &g.rho, &g.grav[0], &g.grav[1], &g.grav[2], &g.host_in[0],
+                   &g.host_in[1], &g.host_in[2], &g.host_in[3], &g.host_acc[0], &g.host_acc[1], &g.host_acc[2]})
+        b->release();
+    for (hipEvent_t& e : g.ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    g.ready = false;
+    g.device = -1;
+}
+
+const char* nbpm_last_error(void) { return g_err; }
+
+int nbpm_set_timing(int on) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g.timing = on != 0;
+    return NBPM_OK;
+}
+
+int nbpm_get_stats(nbpm_stats* out) {
+    if (!out) return fail(NBPM_ERR_ARG, "out is NULL");
+    std::lock_guard<std::mutex> lock(g_mu);
+    *out = g.stats;
+    return NBPM_OK;
+}
+
+int nbpm_deposit_device(const nbpm_params* p, size_t n, const double* x, const double* y,
+                        const double* z, const double* m, double* rho, void* stream) {
+    ENTER();
+    CHK(check_params(p));
+    if (!rho || (n && (!x || !y || !z || !m))) return fail(NBPM_ERR_ARG, "NULL array");
+    return deposit(p, n, x, y, z, m, rho, static_cast<hipStream_t>(stream));
+}
+
+int nbpm_solve_device(const nbpm_params* p, const double* rho, double* gx, double* gy,
+                      double* gz, void* stream) {
+    ENTER();
+    CHK(check_params(p));
+    if (!rho || !gx || !gy || !gz) return fail(NBPM_ERR_ARG, "NULL array");
+    return solve(p, rho, gx, gy, gz, static_cast<hipStream_t>(stream));
+}
+
+int nbpm_interpolate_device(const nbpm_params* p, size_t n, const double* x, const double* y,
+                            const double* z, const double* gx, const double* gy,
+                            const double* gz, double* ax, double* ay, double* az,
+                            void* stream) {
+    ENTER();
+    CHK(check_params(p));
+    if (!gx || !gy || !gz || (n && (!x || !y || !z || !ax || !ay || !az)))
+        return fail(NBPM_ERR_ARG, "NULL array");
+    return interpolate(p, n, x, y, z, gx, gy, gz, ax, ay, az, static_cast<hipStream_t>(stream));
+}
+
+int nbpm_accelerations_device(const nbpm_params* p, size_t n, const double* x, const double* y,
+                              const double* z, const double* m, double* ax, double* ay,
+                              double* az, void* stream) {
+    ENTER();
+    CHK(check_params(p));
+    if (n && (!x || !y || !z || !m || !ax || !ay || !az)) return fail(NBPM_ERR_ARG, "NULL array");
+    return accelerations(p, n, x, y, z, m, ax, ay, az, static_cast<hipStream_t>(stream));
+}
+
+int nbpm_accelerations(const nbpm_params* p, size_t n, const double* x, const double* y,
+                       const double* z, const double* m, double* ax, double* ay, double* az) {
+    ENTER();
+    CHK(check_params(p));
+    if (n == 0) return NBPM_OK;
+    if (!x || !y || !z || !m || !ax || !ay || !az) return fail(NBPM_ERR_ARG, "NULL array");
+    const size_t bytes = sizeof(double) * n;
+    const double* in[4] = {x, y, z, m};
+    for (int c = 0; c < 4; ++c) {
+        CHK(g.host_in[c].ensure(bytes));
+        HIPCHK(hipMemcpyAsync(g.host_in[c].p, in[c], bytes, hipMemcpyHostToDevice, nullptr));
+    }
+    for (Buf& b : g.host_acc) CHK(b.ensure(bytes));
+    CHK(accelerations(p, n, g.host_in[0].as<double>(), g.host_in[1].as<double>(), g.host_in[2].as<double>(),
+                      g.host_in[3].as<double>(), g.host_acc[0].as<double>(), g.host_acc[1].as<double>(),
+                      g.host_acc[2].as<double>(), nullptr));
+    double* out[3] = {ax, ay, az};
+    for (int c = 0; c < 3; ++c) HIPCHK(hipMemcpyAsync(out[c], g.host_acc[c].p, bytes, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return NBPM_OK;
+}
+
+}  // extern "C"

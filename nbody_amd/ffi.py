@@ -178,3 +178,120 @@ def load(device=None):
     if device is not None and not _LIB._inited:
         _LIB.init(device)
     return _LIB
+
+
+# ---------------------------------------------------------------------------------------
+# libnbpm.so: the mesh (long-range) side, include/nbpm.h
+# ---------------------------------------------------------------------------------------
+MESH_LIB_PATH = os.environ.get("NBPM_LIB") or os.path.join(HERE, "lib", "libnbpm.so")
+
+MESH_EXPORTS = (
+    "nbpm_init", "nbpm_shutdown", "nbpm_last_error", "nbpm_set_timing", "nbpm_get_stats",
+    "nbpm_deposit_device", "nbpm_solve_device", "nbpm_interpolate_device",
+    "nbpm_accelerations_device", "nbpm_accelerations",
+)
+
+
+class MeshParams(C.Structure):
+    """nbpm_params."""
+    _fields_ = [("domain_size", C.c_double), ("G", C.c_double), ("mesh_size", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class MeshStats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("deposit_ms", "solve_ms", "interpolate_ms", "total_ms")]
+
+
+class MeshLibrary:
+    """Loaded libnbpm.so.  Construction fails loudly when the shared object is missing."""
+
+    def __init__(self, path=MESH_LIB_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it with `make -C nbody_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path")
+        try:  # same reason as in Library: one HIP runtime per process
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = self.lib = C.CDLL(path)
+        self.path = path
+        L.nbpm_init.argtypes = [C.c_int]
+        L.nbpm_shutdown.restype = None
+        L.nbpm_last_error.restype = C.c_char_p
+        L.nbpm_set_timing.argtypes = [C.c_int]
+        L.nbpm_get_stats.argtypes = [C.POINTER(MeshStats)]
+        P = C.POINTER(MeshParams)
+        L.nbpm_deposit_device.argtypes = [P, C.c_size_t] + [_DP] * 5 + [C.c_void_p]
+        L.nbpm_solve_device.argtypes = [P] + [_DP] * 4 + [C.c_void_p]
+        L.nbpm_interpolate_device.argtypes = [P, C.c_size_t] + [_DP] * 9 + [C.c_void_p]
+        L.nbpm_accelerations_device.argtypes = [P, C.c_size_t] + [_DP] * 7 + [C.c_void_p]
+        L.nbpm_accelerations.argtypes = [P, C.c_size_t] + [_DP] * 7
+        self._inited = False
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NbppError(rc, self.lib.nbpm_last_error().decode(errors="replace"))
+
+    def init(self, device=0):
+        self._check(self.lib.nbpm_init(device))
+        self._inited = True
+        return self
+
+    def shutdown(self):
+        self.lib.nbpm_shutdown()
+        self._inited = False
+
+    def set_timing(self, on=True):
+        self._check(self.lib.nbpm_set_timing(1 if on else 0))
+
+    def stats(self):
+        s = MeshStats()
+        self._check(self.lib.nbpm_get_stats(C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def deposit_device(self, p, x, y, z, m, rho, stream=None):
+        if rho.numel() != p.mesh_size ** 3:
+            raise ValueError("rho must hold mesh_size^3 values")
+        self._check(self.lib.nbpm_deposit_device(C.byref(p), x.numel(), _dev(x), _dev(y), _dev(z),
+                                                 _dev(m), _dev(rho), C.c_void_p(stream or 0)))
+
+    def solve_device(self, p, rho, gx, gy, gz, stream=None):
+        if min(t.numel() for t in (rho, gx, gy, gz)) != p.mesh_size ** 3:
+            raise ValueError("meshes must hold mesh_size^3 values")
+        self._check(self.lib.nbpm_solve_device(C.byref(p), _dev(rho), _dev(gx), _dev(gy), _dev(gz),
+                                               C.c_void_p(stream or 0)))
+
+    def interpolate_device(self, p, x, y, z, gx, gy, gz, ax, ay, az, stream=None):
+        if min(t.numel() for t in (gx, gy, gz)) != p.mesh_size ** 3:
+            raise ValueError("meshes must hold mesh_size^3 values")
+        if min(ax.numel(), ay.numel(), az.numel()) < x.numel():
+            raise ValueError("acceleration arrays shorter than the particle count")
+        self._check(self.lib.nbpm_interpolate_device(
+            C.byref(p), x.numel(), _dev(x), _dev(y), _dev(z), _dev(gx), _dev(gy), _dev(gz),
+            _dev(ax), _dev(ay), _dev(az), C.c_void_p(stream or 0)))
+
+    def accelerations_device(self, p, x, y, z, m, ax, ay, az, stream=None):
+        if min(ax.numel(), ay.numel(), az.numel()) < x.numel():
+            raise ValueError("acceleration arrays shorter than the particle count")
+        self._check(self.lib.nbpm_accelerations_device(
+            C.byref(p), x.numel(), _dev(x), _dev(y), _dev(z), _dev(m), _dev(ax), _dev(ay),
+            _dev(az), C.c_void_p(stream or 0)))
+
+    def accelerations(self, p, x, y, z, m, ax, ay, az):
+        """Host numpy arrays; ax/ay/az are overwritten (nbpm_accelerations)."""
+        self._check(self.lib.nbpm_accelerations(C.byref(p), x.size, _host(x), _host(y), _host(z),
+                                                _host(m), _host(ax), _host(ay), _host(az)))
+
+
+_MESH_LIB = None
+
+
+def load_mesh(device=None):
+    """Process-wide MeshLibrary; `device` given -> also nbpm_init(device)."""
+    global _MESH_LIB
+    if _MESH_LIB is None:
+        _MESH_LIB = MeshLibrary()
+    if device is not None and not _MESH_LIB._inited:
+        _MESH_LIB.init(device)
+    return _MESH_LIB

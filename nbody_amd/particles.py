@@ -86,6 +86,14 @@ class Config:
         p.use_pm = 1 if self.USE_PM else 0
         return p
 
+    def mesh_params(self) -> ffi.MeshParams:
+        """What the mesh solve reads from the configuration (src/integrator.cpp:48, :91, :100)."""
+        p = ffi.MeshParams()
+        p.domain_size = self.DOMAIN_SIZE
+        p.G = self.G
+        p.mesh_size = self.MESH_SIZE
+        return p
+
 
 class ParticleSystem:
     """Host SoA particle state (src/particles.h:26-72) whose compute_pp_forces runs on the GPU."""
@@ -148,6 +156,18 @@ class ParticleSystem:
         arrs = [np.ascontiguousarray(self._view(k)) for k in ("pos_x", "pos_y", "pos_z", "mass")]
         acc = [np.ascontiguousarray(self._view(k)).copy() for k in ("acc_x", "acc_y", "acc_z")]
         lib.accumulate(config.pp_params(), *arrs, *acc)
+        for k, a in zip(("acc_x", "acc_y", "acc_z"), acc):
+            getattr(self, "_" + k)[:n] = a
+
+    def compute_mesh_forces(self, config: Config, mesh_library: ffi.MeshLibrary | None = None):
+        """acc = mesh (PM) acceleration, on the GPU: the sequence bin_and_assign_mass ->
+        compute_gravitational_acceleration -> interpolate_cic_forces of the reference's step
+        (src/integrator.cpp:239-245) for dark matter alone (USE_HYDRO off)."""
+        lib = mesh_library or ffi.load_mesh(device=0)
+        n = self.num_particles
+        arrs = [np.ascontiguousarray(self._view(k)) for k in ("pos_x", "pos_y", "pos_z", "mass")]
+        acc = [np.zeros(n) for _ in range(3)]
+        lib.accelerations(config.mesh_params(), *arrs, *acc)
         for k, a in zip(("acc_x", "acc_y", "acc_z"), acc):
             getattr(self, "_" + k)[:n] = a
 

@@ -11,10 +11,10 @@ from nbody_amd import ffi
 from conftest import ROOT
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "nbpp.h")).read()
+def _declared(header="nbpp.h", prefix="nbpp_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(nbpp_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_library_agree():
@@ -24,6 +24,30 @@ def test_header_and_library_agree():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/nbpp.h but not exported"
     assert sorted(ffi.EXPORTS) == names
+
+
+def test_mesh_header_and_library_agree():
+    names = _declared("nbpm.h", "nbpm_")
+    assert len(names) >= 10
+    lib = ctypes.CDLL(ffi.MESH_LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nbpm.h but not exported"
+    assert sorted(ffi.MESH_EXPORTS) == names
+    assert ctypes.sizeof(ffi.MeshParams) == 2 * 8 + 2 * 4
+    assert ctypes.sizeof(ffi.MeshStats) == 4 * 8
+
+
+def test_mesh_library_has_no_silent_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = ffi.MeshLibrary()
+    with pytest.raises(ffi.NbppError):
+        L.init(0)
+    a = np.zeros(4)
+    with pytest.raises(ffi.NbppError) as e:
+        L.accelerations(nbody_amd.Config().mesh_params(), a, a, a, a, a.copy(), a.copy(), a.copy())
+    assert e.value.code == -3  # NBPM_ERR_NOINIT
 
 
 def test_struct_layouts_match_header():
