@@ -130,6 +130,15 @@ void Config::compute_derived_data() {
     FIXED_DT = DT_FACTOR * (1.0 / std::sqrt(G));
 }
 
+nbpm_params Config::mesh_params() const {
+    nbpm_params p;
+    p.domain_size = DOMAIN_SIZE;
+    p.G = G;
+    p.mesh_size = MESH_SIZE;
+    p.reserved = 0;
+    return p;
+}
+
 nbpp_params Config::pp_params() const {
     nbpp_params p;
     p.domain_size = DOMAIN_SIZE;

@@ -5,6 +5,7 @@
 #pragma once
 #include <string>
 
+#include "../../include/nbpm.h"
 #include "../../include/nbpp.h"
 
 namespace nbh {
@@ -64,6 +65,8 @@ struct Config {
 
     // The scalars compute_pp_forces hoists (src/particles.cpp:143-152) as the library's POD.
     nbpp_params pp_params() const;
+    // What the mesh solve reads (src/integrator.cpp:48, :91, :100).
+    nbpm_params mesh_params() const;
 };
 
 }  // namespace nbh

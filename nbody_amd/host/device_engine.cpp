@@ -16,6 +16,9 @@ void hip_check(hipError_t e, const char* what) {
 void nbpp_check(int rc) {
     if (rc != NBPP_OK) throw std::runtime_error(std::string("libnbpp: ") + nbpp_last_error());
 }
+void nbpm_check(int rc) {
+    if (rc != NBPM_OK) throw std::runtime_error(std::string("libnbpm: ") + nbpm_last_error());
+}
 }  // namespace
 
 DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s) : config_(config) {
@@ -25,6 +28,12 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s) : conf
     for (int c = 0; c < 10; ++c) {
         hip_check(hipMalloc(reinterpret_cast<void**>(&dev_[c]), sizeof(double) * std::max<std::size_t>(n_, 1)), "hipMalloc");
         if (n_) hip_check(hipMemcpy(dev_[c], host[c]->data(), sizeof(double) * n_, hipMemcpyHostToDevice), "upload");
+    }
+    if (config_.USE_PM) {
+        int device = 0;
+        hip_check(hipGetDevice(&device), "hipGetDevice");
+        nbpm_check(nbpm_init(device));
+        nbpm_check(nbpm_set_timing(1));
     }
     cosmo.total_time = 0.0;
     update_cosmology(cosmo, config_);
@@ -39,9 +48,17 @@ DeviceEngine::~DeviceEngine() {
 }
 
 void DeviceEngine::compute_accelerations() {
-    for (int c = 6; c < 9; ++c)
-        hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, nullptr), "zero acc");  // :246-251
-    hip_check(hipStreamSynchronize(nullptr), "sync");
+    if (config_.USE_PM) {                                                               // :239-245
+        const nbpm_params mp = config_.mesh_params();
+        nbpm_check(nbpm_accelerations_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], dev_[6],
+                                             dev_[7], dev_[8], nullptr));
+        nbpm_stats ms;
+        if (nbpm_get_stats(&ms) == NBPM_OK) pm_ms += ms.total_ms;
+    } else {
+        for (int c = 6; c < 9; ++c)
+            hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, nullptr), "zero acc");  // :246-251
+        hip_check(hipStreamSynchronize(nullptr), "sync");
+    }
     if (config_.USE_PP && n_) {                                                         // :254-258
         const nbpp_params p = config_.pp_params();
         nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_,

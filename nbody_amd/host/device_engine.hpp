@@ -1,7 +1,7 @@
-// device_engine.hpp - the simulation loop for PP-only dark matter with all particle state
-// resident in HBM: the reference's SimulationEngine (src/engine.cpp:10-91) and KDK_step
-// (src/integrator.cpp:215-275) reduced to the dark-matter, particle-particle parts, driving
-// libnbpp's device entry points.  Positions, velocities and accelerations cross PCIe once in
+// device_engine.hpp - the simulation loop for dark matter with all particle state resident
+// in HBM: the reference's SimulationEngine (src/engine.cpp:10-91) and KDK_step
+// (src/integrator.cpp:215-275) reduced to the dark-matter parts (mesh force through libnbpm,
+// particle-particle force through libnbpp; no gas), driving the libraries' device entry points.  Positions, velocities and accelerations cross PCIe once in
 // each direction (upload at construction, download on request) instead of twice per step.
 #pragma once
 #include <cstddef>
@@ -34,9 +34,10 @@ class DeviceEngine {
     Cosmology cosmo;
     double max_accel_sq = 1e-9;
     double pp_ms = 0.0;                  // accumulated device time of the PP force calls
+    double pm_ms = 0.0;                  // accumulated device time of the mesh force calls
 
    private:
-    void compute_accelerations();        // src/integrator.cpp:246-269, mesh part absent
+    void compute_accelerations();        // src/integrator.cpp:236-269 for dark matter alone
     double gravity_timestep() const;     // src/particles.cpp:386-391
     Config config_;
     std::size_t n_ = 0;

@@ -135,7 +135,7 @@ static void test_accumulate_and_contract() {
     std::vector<double> once = sys.acc_x;
     sys.compute_pp_forces(config);  // acc += : second call doubles
     for (std::size_t i = 0; i < sys.num_particles; ++i) REQUIRE(approx(sys.acc_x[i], 2.0 * once[i], 1e-14));
-    compute_pp_accelerations(sys, config);  // zero-fills first
+    compute_accelerations(sys, config);  // zero-fills first
     double mx = 1e-9;
     for (std::size_t i = 0; i < sys.num_particles; ++i) {
         REQUIRE(approx(sys.acc_x[i], once[i], 1e-14));
@@ -145,18 +145,18 @@ static void test_accumulate_and_contract() {
     REQUIRE(sys.get_gravity_timestep(config) ==
             std::sqrt(config.SOFTENING_SQUARED) / std::sqrt(mx) * config.GRAVITY_DT_FACTOR);
     config.STANDING_PARTICLES = true;  // src/integrator.cpp:263-269
-    compute_pp_accelerations(sys, config);
+    compute_accelerations(sys, config);
     REQUIRE(sys.max_accel_sq == 1e-9);
     for (std::size_t i = 0; i < sys.num_particles; ++i) REQUIRE(sys.acc_x[i] == 0.0);
     config.STANDING_PARTICLES = false;
     config.USE_PP = false;             // src/integrator.cpp:254
-    compute_pp_accelerations(sys, config);
+    compute_accelerations(sys, config);
     REQUIRE(sys.max_accel_sq == 1e-9);
     // total momentum change of a KDK step is zero (pairwise antisymmetry)
     config.USE_PP = true;
     config.EXPANDING_UNIVERSE = false;
     Cosmology cosmo;
-    compute_pp_accelerations(sys, config);
+    compute_accelerations(sys, config);
     KDK_step(sys, cosmo, config.FIXED_DT, config);
     double px = 0, scale = 0;
     for (std::size_t i = 0; i < sys.num_particles; ++i) {
@@ -199,7 +199,7 @@ static int run_kdk(const char* in_path, const char* out_path, int steps, double 
         std::printf("device-resident: %ld cycles, PP %.3f ms total\n", engine.cycle_count, engine.pp_ms);
     } else {
         update_cosmology(cosmo, config);
-        compute_pp_accelerations(sys, config);  // initial accelerations, as src/ics.cpp:305-346
+        compute_accelerations(sys, config);  // initial accelerations, as src/ics.cpp:305-346
         double cur = config.USE_ADAPTIVE_DT ? std::min(sys.get_gravity_timestep(config), config.FIXED_DT)
                                             : config.FIXED_DT;
         for (int s = 0; s < steps; ++s) {
@@ -255,9 +255,11 @@ int main(int argc, char** argv) {
             DeviceEngine engine(config, dm);
             std::printf("cycle 0: a=%.6f dt=%.6e max|a|^2=%.6e\n", engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq);
             const ExitStatus st = engine.run();
-            std::printf("cycle %ld: a=%.6f dt=%.6e max|a|^2=%.6e  PP %.3f ms/cycle  exit=%d\n", engine.cycle_count,
-                        engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq,
-                        engine.pp_ms / (engine.cycle_count + 1), static_cast<int>(st));
+            std::printf("cycle %ld: a=%.6f dt=%.6e max|a|^2=%.6e  PP %.3f ms/cycle  mesh %.3f ms/cycle  exit=%d\n",
+                        engine.cycle_count, engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq,
+                        engine.pp_ms / (engine.cycle_count + 1), engine.pm_ms / (engine.cycle_count + 1),
+                        static_cast<int>(st));
+            nbpm_shutdown();
             nbpp_shutdown();
             return 0;
         }
@@ -280,6 +282,7 @@ int main(int argc, char** argv) {
                 std::printf("%s (%d failures)\n", g_failures ? "FAILED" : "ALL PASSED", g_failures);
                 rc = g_failures ? 1 : 0;
             }
+            nbpm_shutdown();
             nbpp_shutdown();
             return rc;
         }

@@ -61,11 +61,15 @@ void calculate_max_acceleration(ParticleSystem& dm) {
     dm.max_accel_sq = local_max;
 }
 
-void compute_pp_accelerations(ParticleSystem& dm, const Config& config) {
+void compute_accelerations(ParticleSystem& dm, const Config& config) {
     dm.bin_and_assign_mass(config);
-    std::fill(dm.acc_x.begin(), dm.acc_x.end(), 0.0);
-    std::fill(dm.acc_y.begin(), dm.acc_y.end(), 0.0);
-    std::fill(dm.acc_z.begin(), dm.acc_z.end(), 0.0);
+    if (config.USE_PM) {
+        dm.compute_mesh_forces(config);   // overwrites acc, as interpolate_cic_forces does
+    } else {
+        std::fill(dm.acc_x.begin(), dm.acc_x.end(), 0.0);
+        std::fill(dm.acc_y.begin(), dm.acc_y.end(), 0.0);
+        std::fill(dm.acc_z.begin(), dm.acc_z.end(), 0.0);
+    }
     if (config.USE_PP) dm.compute_pp_forces(config);
     if (!config.STANDING_PARTICLES) {
         calculate_max_acceleration(dm);
@@ -83,7 +87,7 @@ void KDK_step(ParticleSystem& dm, Cosmology& cosmo, double dt, const Config& con
     apply_dm_drift(dm, dt, config.DOMAIN_SIZE);
     cosmo.total_time += dt;
     update_cosmology(cosmo, config);
-    compute_pp_accelerations(dm, config);
+    compute_accelerations(dm, config);
     apply_dm_kick(dm, dt / 2.0, cosmo.scale_factor, cosmo.hubble_param);
 }
 

@@ -35,6 +35,14 @@ void ParticleSystem::compute_pp_forces(const Config& config) {
     if (rc != NBPP_OK) throw std::runtime_error(std::string("libnbpp: ") + nbpp_last_error());
 }
 
+void ParticleSystem::compute_mesh_forces(const Config& config) {
+    const nbpm_params p = config.mesh_params();
+    if (nbpm_init(0) != NBPM_OK) throw std::runtime_error(std::string("libnbpm: ") + nbpm_last_error());
+    const int rc = nbpm_accelerations(&p, num_particles, pos_x.data(), pos_y.data(), pos_z.data(),
+                                      mass.data(), acc_x.data(), acc_y.data(), acc_z.data());
+    if (rc != NBPM_OK) throw std::runtime_error(std::string("libnbpm: ") + nbpm_last_error());
+}
+
 double ParticleSystem::get_gravity_timestep(const Config& config) const {
     if (num_particles == 0) return std::numeric_limits<double>::infinity();
     const double dt_grav = std::sqrt(config.SOFTENING_SQUARED) / std::sqrt(max_accel_sq);

@@ -1,6 +1,6 @@
 // particles.hpp - host SoA dark-matter state with the reference's ParticleSystem interface for
 // the particle-particle path (src/particles.h:26-72).  compute_pp_forces hands the arrays to
-// libnbpp; there is no host implementation of the force.
+// libnbpp and libnbpm; there is no host implementation of the forces.
 #pragma once
 #include <cstddef>
 #include <vector>
@@ -24,9 +24,14 @@ class ParticleSystem {
     void add_particle(double px, double py, double pz, double vx, double vy, double vz, double m);
 
     // The reference builds its CIC density and its linked list here (src/particles.cpp:47-100).
-    // libnbpp bins on the GPU inside compute_pp_forces, and the mesh side is outside this
-    // engine's scope, so this only validates that positions are finite.
+    // libnbpp bins on the GPU inside compute_pp_forces and libnbpm assigns the density inside
+    // compute_mesh_forces, so this only validates that positions are finite.
     void bin_and_assign_mass(const Config& config);
+
+    // acc = mesh (PM) acceleration, on the GPU: density assignment, Poisson solve and
+    // interpolate_cic_forces (src/particles.cpp:47-131, src/integrator.cpp:47-132) for dark
+    // matter alone.  Throws std::runtime_error carrying nbpm_last_error() on failure.
+    void compute_mesh_forces(const Config& config);
 
     // acc += PP / P3M short-range acceleration (src/particles.cpp:133-367), on the GPU.
     // Throws std::runtime_error carrying nbpp_last_error() on failure.
