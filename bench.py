@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--per-lane", type=int, default=0)
     ap.add_argument("--force-kernel", type=int, default=0)
     ap.add_argument("--p3m-radius", type=int, default=0)
+    ap.add_argument("--with-mesh", action="store_true",
+                    help="p3m mode, one GPU: a step is the whole force phase, mesh force "
+                         "(libnbpm) then short range accumulated onto it")
     ap.add_argument("--ordered", action="store_true",
                     help="bitwise-reproducible ordered-pair kernel (NBPP_OPT_DETERMINISTIC)")
     args = ap.parse_args()
@@ -129,7 +132,22 @@ def main():
     use_pairs = world > 1 and not use_pm and not args.ordered
     work = [None]
 
+    mesh = None
+    if args.with_mesh:
+        if not use_pm or world != 1:
+            raise SystemExit("--with-mesh needs --mode p3m on one GPU")
+        mesh = nbody_amd.load_mesh(device=local_rank)
+        mesh.set_timing(True)
+        mesh_params = config.mesh_params()
+    mesh_ms = []
+
     def step():
+        if mesh is not None:   # src/integrator.cpp:239-258: the mesh force overwrites, PP adds
+            x, y, z = parts.gather_positions()
+            mesh.accelerations_device(mesh_params, x, y, z, mass, *acc, stream=stream)
+            mesh_ms.append(mesh.stats()["total_ms"])
+            lib.accumulate_device(p, x, y, z, mass, *acc, stream=stream)
+            return lib.stats()
         if use_pairs:
             work[0] = force_evaluation_pairs(parts, mass, acc, compute_pairs, work[0])
         else:
@@ -171,6 +189,9 @@ def main():
             pairs_per_step = accepted_total
             flops = FLOPS_PER_PAIR_P3M
             workload = f"P3M short range, {n_side}^3 particles, mesh {n_side}, cutoff 2.5 cells"
+            if mesh is not None:
+                workload = f"P3M force phase (mesh force + short range), {n_side}^3 particles, " \
+                           f"mesh {n_side}, cutoff 2.5 cells"
         else:
             pairs_per_step = float(n) * float(n - 1)
             flops = FLOPS_PER_PAIR_DIRECT
@@ -214,6 +235,8 @@ def main():
                          "subtiles_wrapped_frac": (st.get("subtiles_wrapped", 0) /
                                                    max(1, st.get("subtiles_total", 0)))},
         }
+        if mesh is not None:
+            line["config"]["mesh_force_ms"] = float(np.mean(mesh_ms[args.warmup:]))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(p, pos, m, args.mode)
         print(json.dumps(line), flush=True)
