@@ -295,3 +295,125 @@ def load_mesh(device=None):
     if device is not None and not _MESH_LIB._inited:
         _MESH_LIB.init(device)
     return _MESH_LIB
+
+
+# ---------------------------------------------------------------------------------------
+# libnbgas.so: the gas (HLL hydro) side, include/nbgas.h
+# ---------------------------------------------------------------------------------------
+GAS_LIB_PATH = os.environ.get("NBGAS_LIB") or os.path.join(HERE, "lib", "libnbgas.so")
+
+GAS_EXPORTS = (
+    "nbgas_init", "nbgas_shutdown", "nbgas_last_error", "nbgas_update_primitives_device",
+    "nbgas_hydro_step_device", "nbgas_cfl_timestep_device", "nbgas_kick_device",
+    "nbgas_total_density_device", "nbgas_initialize_device",
+)
+
+GAS_FIELDS = ("density", "momentum_x", "momentum_y", "momentum_z", "energy",
+              "pressure", "velocity_x", "velocity_y", "velocity_z")
+
+
+class GasParams(C.Structure):
+    """nbgas_params."""
+    _fields_ = [("cell_size", C.c_double), ("gamma", C.c_double), ("cfl_safety_factor", C.c_double),
+                ("mesh_size", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GasState(C.Structure):
+    """nbgas_state: nine device pointers."""
+    _fields_ = [(k, _DP) for k in GAS_FIELDS]
+
+
+class GasLibrary:
+    """Loaded libnbgas.so.  Construction fails loudly when the shared object is missing."""
+
+    def __init__(self, path=GAS_LIB_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it with `make -C nbody_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path")
+        try:  # same reason as in Library: one HIP runtime per process
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = self.lib = C.CDLL(path)
+        self.path = path
+        P, S = C.POINTER(GasParams), C.POINTER(GasState)
+        L.nbgas_init.argtypes = [C.c_int]
+        L.nbgas_shutdown.restype = None
+        L.nbgas_last_error.restype = C.c_char_p
+        L.nbgas_update_primitives_device.argtypes = [P, S, C.c_void_p]
+        L.nbgas_hydro_step_device.argtypes = [P, S, C.c_double, C.c_void_p]
+        L.nbgas_cfl_timestep_device.argtypes = [P, S, C.POINTER(C.c_double), C.c_void_p]
+        L.nbgas_kick_device.argtypes = [P, S] + [_DP] * 3 + [C.c_double] * 3 + [C.c_void_p]
+        L.nbgas_total_density_device.argtypes = [P, S, _DP, _DP, C.c_void_p]
+        L.nbgas_initialize_device.argtypes = [P, S] + [_DP] * 4 + [C.c_double] * 3 + [C.c_int, C.c_double,
+                                                                                     C.c_void_p]
+        self._inited = False
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NbppError(rc, self.lib.nbgas_last_error().decode(errors="replace"))
+
+    def init(self, device=0):
+        self._check(self.lib.nbgas_init(device))
+        self._inited = True
+        return self
+
+    def shutdown(self):
+        self.lib.nbgas_shutdown()
+        self._inited = False
+
+    @staticmethod
+    def state(tensors):
+        """nbgas_state over a dict of nine torch CUDA tensors keyed by GAS_FIELDS."""
+        s = GasState()
+        for k in GAS_FIELDS:
+            setattr(s, k, _dev(tensors[k]))
+        return s
+
+    def update_primitives_device(self, p, tensors, stream=None):
+        s = self.state(tensors)
+        self._check(self.lib.nbgas_update_primitives_device(C.byref(p), C.byref(s), C.c_void_p(stream or 0)))
+
+    def hydro_step_device(self, p, tensors, dt, stream=None):
+        s = self.state(tensors)
+        self._check(self.lib.nbgas_hydro_step_device(C.byref(p), C.byref(s), dt, C.c_void_p(stream or 0)))
+
+    def cfl_timestep_device(self, p, tensors, stream=None):
+        s = self.state(tensors)
+        out = C.c_double(0.0)
+        self._check(self.lib.nbgas_cfl_timestep_device(C.byref(p), C.byref(s), C.byref(out),
+                                                       C.c_void_p(stream or 0)))
+        return out.value
+
+    def kick_device(self, p, tensors, grav, dt, scale_factor, hubble, stream=None):
+        s = self.state(tensors)
+        self._check(self.lib.nbgas_kick_device(C.byref(p), C.byref(s), _dev(grav[0]), _dev(grav[1]),
+                                               _dev(grav[2]), dt, scale_factor, hubble,
+                                               C.c_void_p(stream or 0)))
+
+    def total_density_device(self, p, tensors, dm_density, total, stream=None):
+        s = self.state(tensors)
+        self._check(self.lib.nbgas_total_density_device(C.byref(p), C.byref(s), _dev(dm_density),
+                                                        _dev(total), C.c_void_p(stream or 0)))
+
+    def initialize_device(self, p, tensors, dm_density, disp, mass_ratio, hubble, growth_f,
+                          internal_energy, standing=False, stream=None):
+        s = self.state(tensors)
+        self._check(self.lib.nbgas_initialize_device(
+            C.byref(p), C.byref(s), _dev(dm_density), _dev(disp[0]), _dev(disp[1]), _dev(disp[2]),
+            mass_ratio, hubble, growth_f, 1 if standing else 0, internal_energy,
+            C.c_void_p(stream or 0)))
+
+
+_GAS_LIB = None
+
+
+def load_gas(device=None):
+    """Process-wide GasLibrary; `device` given -> also nbgas_init(device)."""
+    global _GAS_LIB
+    if _GAS_LIB is None:
+        _GAS_LIB = GasLibrary()
+    if device is not None and not _GAS_LIB._inited:
+        _GAS_LIB.init(device)
+    return _GAS_LIB

@@ -16,7 +16,7 @@ from . import ffi
 
 @dataclass
 class Config:
-    """Fields and defaults of reference src/config.h:5-50 that the PP path reads."""
+    """Fields and defaults of reference src/config.h:5-50 that the gravity step reads."""
     DOMAIN_SIZE: float = 1.0
     MESH_SIZE: int = 32
     OMEGA_BARYON: float = 0.045
@@ -29,6 +29,9 @@ class Config:
     CUTOFF_TRANSITION_WIDTH_FACTOR: float = 0.2
     DT_FACTOR: float = 1e-3
     GRAVITY_DT_FACTOR: float = 0.2
+    USE_HYDRO: bool = True
+    GAMMA: float = 5.0 / 3.0
+    CFL_SAFETY_FACTOR: float = 0.5
     # derived (src/config.h:43-50)
     G: float = 0.0
     CELL_SIZE: float = 0.0
@@ -84,6 +87,15 @@ class Config:
         p.cell_size = self.CELL_SIZE
         p.mesh_size = self.MESH_SIZE
         p.use_pm = 1 if self.USE_PM else 0
+        return p
+
+    def gas_params(self) -> ffi.GasParams:
+        """What the gas solver reads from the configuration (src/gas.cpp:191, :251, :322)."""
+        p = ffi.GasParams()
+        p.cell_size = self.CELL_SIZE
+        p.gamma = self.GAMMA
+        p.cfl_safety_factor = self.CFL_SAFETY_FACTOR
+        p.mesh_size = self.MESH_SIZE
         return p
 
     def mesh_params(self) -> ffi.MeshParams:

@@ -95,4 +95,5 @@ def zeldovich_particles(n_per_side=32, mesh_size=32, seed=42, domain_size=1.0, b
         dd = d[ix, iy, iz]                                                           # :185-191
         pos.append(np.ascontiguousarray(np.fmod(qq + dd + domain_size, domain_size).ravel()))
         vel.append(np.ascontiguousarray((H * dd * f_growth).ravel()))                # :200-208
-    return pos, vel, {"scale_factor": a, "hubble_param": H, "growth_f": f_growth, "A": A}
+    return pos, vel, {"scale_factor": a, "hubble_param": H, "growth_f": f_growth, "A": A,
+                      "displacement": disp}

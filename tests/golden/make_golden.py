@@ -89,7 +89,22 @@ def main():
         "p0_acc_initial_pm_plus_pp": [0.00038592991125482439, -0.0018989432424388109,
                                       -0.00086020514888652676],
         "max_accel_sq": 2.5834272123748411e-05,
+        "p0_acc_after_one_step": [0.00066809247978902883, -0.0033187059537092838,
+                                  -0.0015552108792028102],
+        "after_one_step_source": "KDK_step (src/integrator.cpp:215-275) with dt = FIXED_DT on the "
+                                 "state of initialize_state, /root/reference/simulation.ini "
+                                 "(mesh + short range + gas)",
     }
+    kat["hll_solver"] = {  # tests/test_hydro.cpp:29-67; S_R_minus_S_L is only read in the mixed regime
+        "source": "tests/test_hydro.cpp:29-67",
+        "cases": [
+            {"S_L": 1.5, "S_R": 3.0, "S_R_minus_S_L": 0.0, "FL": 10.0, "FR": 20.0, "UL": 1.0,
+             "UR": 2.0, "flux": 10.0},
+            {"S_L": -3.0, "S_R": -1.5, "S_R_minus_S_L": 0.0, "FL": 10.0, "FR": 20.0, "UL": 1.0,
+             "UR": 2.0, "flux": 20.0},
+            {"S_L": -1.0, "S_R": 2.0, "S_R_minus_S_L": 3.0, "FL": 4.0, "FR": 10.0, "UL": 2.0,
+             "UR": 5.0, "flux": 4.0},
+        ]}
     with open(os.path.join(HERE, "reference_kat.json"), "w") as f:
         json.dump(kat, f, indent=1)
 

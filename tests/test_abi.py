@@ -50,6 +50,22 @@ def test_mesh_library_has_no_silent_fallback_without_gpu():
     assert e.value.code == -3  # NBPM_ERR_NOINIT
 
 
+def test_gas_header_and_library_agree():
+    names = _declared("nbgas.h", "nbgas_")
+    assert len(names) >= 9
+    lib = ctypes.CDLL(ffi.GAS_LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nbgas.h but not exported"
+    assert sorted(ffi.GAS_EXPORTS) == names
+    assert ctypes.sizeof(ffi.GasParams) == 3 * 8 + 2 * 4
+    assert ctypes.sizeof(ffi.GasState) == 9 * 8
+    L = ffi.GasLibrary()
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(ffi.NbppError):
+            L.init(0)                     # no device: fails loudly, no CPU path
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(ffi.Params) == 9 * 8 + 2 * 4
     assert ctypes.sizeof(ffi.Stats) == 5 * 8 + 7 * 8 + 2 * 4
