@@ -130,6 +130,16 @@ void Config::compute_derived_data() {
     FIXED_DT = DT_FACTOR * (1.0 / std::sqrt(G));
 }
 
+nbgas_params Config::gas_params() const {
+    nbgas_params p;
+    p.cell_size = CELL_SIZE;
+    p.gamma = GAMMA;
+    p.cfl_safety_factor = CFL_SAFETY_FACTOR;
+    p.mesh_size = MESH_SIZE;
+    p.reserved = 0;
+    return p;
+}
+
 nbpm_params Config::mesh_params() const {
     nbpm_params p;
     p.domain_size = DOMAIN_SIZE;

@@ -5,6 +5,7 @@
 #pragma once
 #include <string>
 
+#include "../../include/nbgas.h"
 #include "../../include/nbpm.h"
 #include "../../include/nbpp.h"
 
@@ -67,6 +68,8 @@ struct Config {
     nbpp_params pp_params() const;
     // What the mesh solve reads (src/integrator.cpp:48, :91, :100).
     nbpm_params mesh_params() const;
+    // What the gas solver reads (src/gas.cpp:191, :251, :322).
+    nbgas_params gas_params() const;
 };
 
 }  // namespace nbh

@@ -19,56 +19,111 @@ void nbpp_check(int rc) {
 void nbpm_check(int rc) {
     if (rc != NBPM_OK) throw std::runtime_error(std::string("libnbpm: ") + nbpm_last_error());
 }
+void nbgas_check(int rc) {
+    if (rc != NBGAS_OK) throw std::runtime_error(std::string("libnbgas: ") + nbgas_last_error());
+}
 }  // namespace
 
-DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s) : config_(config) {
+DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const ZeldovichField* field)
+    : config_(config) {
     n_ = s.num_particles;
+    cells_ = static_cast<std::size_t>(config_.MESH_SIZE) * config_.MESH_SIZE * config_.MESH_SIZE;
     const std::vector<double>* host[10] = {&s.pos_x, &s.pos_y, &s.pos_z, &s.vel_x, &s.vel_y,
                                            &s.vel_z, &s.acc_x, &s.acc_y, &s.acc_z, &s.mass};
     for (int c = 0; c < 10; ++c) {
         hip_check(hipMalloc(reinterpret_cast<void**>(&dev_[c]), sizeof(double) * std::max<std::size_t>(n_, 1)), "hipMalloc");
         if (n_) hip_check(hipMemcpy(dev_[c], host[c]->data(), sizeof(double) * n_, hipMemcpyHostToDevice), "upload");
     }
-    if (config_.USE_PM) {
-        int device = 0;
-        hip_check(hipGetDevice(&device), "hipGetDevice");
+    int device = 0;
+    hip_check(hipGetDevice(&device), "hipGetDevice");
+    for (void*& e : ev_) hip_check(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)), "hipEventCreate");
+    const bool meshes = config_.USE_PM || config_.USE_HYDRO;
+    if (meshes) {
         nbpm_check(nbpm_init(device));
         nbpm_check(nbpm_set_timing(1));
+        for (double*& m : mesh_) hip_check(hipMalloc(reinterpret_cast<void**>(&m), sizeof(double) * cells_), "hipMalloc");
     }
     cosmo.total_time = 0.0;
     update_cosmology(cosmo, config_);
+    if (config_.USE_HYDRO) {                                                 // src/ics.cpp:241-288
+        if (!field || field->dx.size() != cells_)
+            throw std::runtime_error("USE_HYDRO needs the displacement field of the initial conditions");
+        if (n_ == 0) throw std::runtime_error("USE_HYDRO needs dark-matter particles (src/ics.cpp:250)");
+        nbgas_check(nbgas_init(device));
+        for (double*& m : gas_) hip_check(hipMalloc(reinterpret_cast<void**>(&m), sizeof(double) * cells_), "hipMalloc");
+        const nbpm_params mp = config_.mesh_params();
+        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], nullptr));
+        // the displacement field is only needed now: stage it in the gravity meshes
+        const std::vector<double>* disp[3] = {&field->dx, &field->dy, &field->dz};
+        for (int c = 0; c < 3; ++c)
+            hip_check(hipMemcpy(mesh_[2 + c], disp[c]->data(), sizeof(double) * cells_, hipMemcpyHostToDevice), "upload");
+        const double total_dm_mass = n_ * config_.DM_PARTICLE_MASS;          // :251-252
+        const double mass_ratio = config_.GAS_TOTAL_MASS / total_dm_mass;
+        const double u0 = internal_energy_from_temperature(config_.INITIAL_GAS_TEMPERATURE_K, config_.HUBBLE_PARAM,
+                                                           config_.BOX_SIZE_MPC, config_.DOMAIN_SIZE, config_.GAMMA);
+        const nbgas_params gp = config_.gas_params();
+        const nbgas_state gs = gas_state();
+        nbgas_check(nbgas_initialize_device(&gp, &gs, mesh_[0], mesh_[2], mesh_[3], mesh_[4], mass_ratio,
+                                            cosmo.hubble_param, field->f, config_.STANDING_PARTICLES ? 1 : 0, u0,
+                                            nullptr));
+    }
     compute_accelerations();
-    current_dt = config_.USE_ADAPTIVE_DT ? std::min(gravity_timestep(), config_.FIXED_DT)
-                                         : config_.FIXED_DT;               // engine.cpp:18-22
+    current_dt = next_timestep();                                            // src/engine.cpp:16-22
 }
 
 DeviceEngine::~DeviceEngine() {
+    for (void* e : ev_)
+        if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     for (double* p : dev_)
+        if (p) (void)hipFree(p);
+    for (double* p : gas_)
+        if (p) (void)hipFree(p);
+    for (double* p : mesh_)
         if (p) (void)hipFree(p);
 }
 
+nbgas_state DeviceEngine::gas_state() const {
+    return nbgas_state{gas_[0], gas_[1], gas_[2], gas_[3], gas_[4], gas_[5], gas_[6], gas_[7], gas_[8]};
+}
+
 void DeviceEngine::compute_accelerations() {
-    if (config_.USE_PM) {                                                               // :239-245
+    if (config_.USE_PM || config_.USE_HYDRO) {                               // :239-245
+        // bin_and_assign_mass, total density, Poisson solve; the gas kick reads the meshes too
         const nbpm_params mp = config_.mesh_params();
-        nbpm_check(nbpm_accelerations_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], dev_[6],
-                                             dev_[7], dev_[8], nullptr));
-        nbpm_stats ms;
-        if (nbpm_get_stats(&ms) == NBPM_OK) pm_ms += ms.total_ms;
-    } else {
+        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), nullptr), "event");
+        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], nullptr));
+        const double* source = mesh_[0];
+        if (config_.USE_HYDRO) {                                             // :57-59
+            const nbgas_params gp = config_.gas_params();
+            const nbgas_state gs = gas_state();
+            nbgas_check(nbgas_total_density_device(&gp, &gs, mesh_[0], mesh_[1], nullptr));
+            source = mesh_[1];
+        }
+        nbpm_check(nbpm_solve_device(&mp, source, mesh_[2], mesh_[3], mesh_[4], nullptr));
+        if (config_.USE_PM)
+            nbpm_check(nbpm_interpolate_device(&mp, n_, dev_[0], dev_[1], dev_[2], mesh_[2], mesh_[3], mesh_[4],
+                                               dev_[6], dev_[7], dev_[8], nullptr));
+        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), nullptr), "event");
+        hip_check(hipEventSynchronize(static_cast<hipEvent_t>(ev_[1])), "event");
+        float ms = 0.0f;
+        hip_check(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(ev_[0]), static_cast<hipEvent_t>(ev_[1])), "event");
+        pm_ms += ms;
+    }
+    if (!config_.USE_PM) {                                                   // :246-251
         for (int c = 6; c < 9; ++c)
-            hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, nullptr), "zero acc");  // :246-251
+            hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, nullptr), "zero acc");
         hip_check(hipStreamSynchronize(nullptr), "sync");
     }
-    if (config_.USE_PP && n_) {                                                         // :254-258
+    if (config_.USE_PP && n_) {                                              // :254-258
         const nbpp_params p = config_.pp_params();
         nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_,
                                           dev_[6], dev_[7], dev_[8], nullptr));
         nbpp_stats st;
         if (nbpp_get_stats(&st) == NBPP_OK) pp_ms += st.total_ms;
     }
-    if (!config_.STANDING_PARTICLES) {                                                  // :261-262
+    if (!config_.STANDING_PARTICLES) {                                       // :261-262
         nbpp_check(nbpp_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, nullptr));
-    } else {                                                                            // :263-269
+    } else {                                                                 // :263-269
         nbpp_check(nbpp_max_accel_sq_device(0, nullptr, nullptr, nullptr, &max_accel_sq, nullptr));
         for (int c = 6; c < 9; ++c)
             hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, nullptr), "zero acc");
@@ -82,21 +137,50 @@ double DeviceEngine::gravity_timestep() const {
     return std::sqrt(config_.SOFTENING_SQUARED) / std::sqrt(max_accel_sq) * config_.GRAVITY_DT_FACTOR;
 }
 
+double DeviceEngine::next_timestep() {
+    if (!config_.USE_ADAPTIVE_DT) return config_.FIXED_DT;
+    double dt_cfl = std::numeric_limits<double>::infinity();                 // src/gas.cpp:302
+    if (config_.USE_HYDRO) {
+        const nbgas_params gp = config_.gas_params();
+        const nbgas_state gs = gas_state();
+        nbgas_check(nbgas_cfl_timestep_device(&gp, &gs, &dt_cfl, nullptr));
+    }
+    return std::min({dt_cfl, gravity_timestep(), config_.FIXED_DT});
+}
+
 void DeviceEngine::step() {
     const double dt = current_dt;
+    const nbgas_params gp = config_.gas_params();
+    const nbgas_state gs = gas_state();
     update_cosmology(cosmo, config_);                                                   // integrator.cpp:216
+    if (config_.USE_HYDRO)                                                              // :219-220
+        nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,
+                                      cosmo.hubble_param, nullptr));
     nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
                                 cosmo.scale_factor, cosmo.hubble_param, nullptr));      // :221
     nbpp_check(nbpp_drift_device(n_, dev_[0], dev_[1], dev_[2], dev_[3], dev_[4], dev_[5], dt,
                                  config_.DOMAIN_SIZE, nullptr));                        // :224
+    if (config_.USE_HYDRO) {                                                            // :227-230
+        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), nullptr), "event");
+        nbgas_check(nbgas_hydro_step_device(&gp, &gs, dt, nullptr));
+        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), nullptr), "event");
+    }
     cosmo.total_time += dt;                                                             // :233
     update_cosmology(cosmo, config_);                                                   // :234
     compute_accelerations();                                                            // :236-269
+    if (config_.USE_HYDRO)                                                              // :272-273
+        nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,
+                                      cosmo.hubble_param, nullptr));
     nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
                                 cosmo.scale_factor, cosmo.hubble_param, nullptr));      // :274
     ++cycle_count;
-    if (config_.USE_ADAPTIVE_DT)                                                        // engine.cpp:47-51
-        current_dt = std::min(gravity_timestep(), config_.FIXED_DT);
+    if (config_.USE_HYDRO) {
+        hip_check(hipEventSynchronize(static_cast<hipEvent_t>(ev_[3])), "event");
+        float ms = 0.0f;
+        hip_check(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(ev_[2]), static_cast<hipEvent_t>(ev_[3])), "event");
+        gas_ms += ms;
+    }
+    if (config_.USE_ADAPTIVE_DT) current_dt = next_timestep();                          // engine.cpp:47-51
     needs_more_cycles = cosmo.scale_factor < config_.MAX_SCALE_FACTOR &&
                         cycle_count < config_.MAX_CYCLES;                               // :53-54
 }
@@ -118,6 +202,14 @@ void DeviceEngine::download(ParticleSystem& out) {
     }
     out.num_particles = n_;
     out.max_accel_sq = max_accel_sq;
+}
+
+void DeviceEngine::download_gas(std::vector<double> (&out)[9]) {
+    hip_check(hipDeviceSynchronize(), "sync");
+    for (int c = 0; c < 9; ++c) {
+        out[c].resize(gas_[c] ? cells_ : 0);
+        if (gas_[c]) hip_check(hipMemcpy(out[c].data(), gas_[c], sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
+    }
 }
 
 }  // namespace nbh

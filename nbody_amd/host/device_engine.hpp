@@ -1,12 +1,15 @@
-// device_engine.hpp - the simulation loop for dark matter with all particle state resident
-// in HBM: the reference's SimulationEngine (src/engine.cpp:10-91) and KDK_step
-// (src/integrator.cpp:215-275) reduced to the dark-matter parts (mesh force through libnbpm,
-// particle-particle force through libnbpp; no gas), driving the libraries' device entry points.  Positions, velocities and accelerations cross PCIe once in
+// device_engine.hpp - the simulation loop with all state resident in HBM: the reference's
+// SimulationEngine (src/engine.cpp:10-91) and KDK_step (src/integrator.cpp:215-275), driving the
+// device entry points of libnbpp (particle-particle force, kick, drift), libnbpm (mesh force)
+// and libnbgas (gas).  Positions, velocities, accelerations and the gas meshes cross PCIe once in
 // each direction (upload at construction, download on request) instead of twice per step.
+// No snapshots, no logging.
 #pragma once
 #include <cstddef>
+#include <vector>
 
 #include "config.hpp"
+#include "ics.hpp"
 #include "integrator.hpp"
 #include "particles.hpp"
 
@@ -17,8 +20,10 @@ enum class ExitStatus { ReachedMaxScaleFactor, ReachedMaxCycles, UserAborted }; 
 class DeviceEngine {
    public:
     // Uploads the host state and computes the initial accelerations and time step, as the
-    // reference's constructor does through initialize_state (src/engine.cpp:16-22).
-    DeviceEngine(const Config& config, const ParticleSystem& initial);
+    // reference's constructor does through initialize_state (src/engine.cpp:16-22).  With
+    // USE_HYDRO the gas starts from the displacement field `field` (src/ics.cpp:241-288), which
+    // must then be given.
+    DeviceEngine(const Config& config, const ParticleSystem& initial, const ZeldovichField* field = nullptr);
     ~DeviceEngine();
     DeviceEngine(const DeviceEngine&) = delete;
     DeviceEngine& operator=(const DeviceEngine&) = delete;
@@ -26,7 +31,10 @@ class DeviceEngine {
     void step();                         // src/engine.cpp:36-54 (no I/O, no logging)
     ExitStatus run();                    // src/engine.cpp:78-91
     void request_stop() { stop_requested_ = true; }
-    void download(ParticleSystem& out);  // blocking copy of the full state back to the host
+    void download(ParticleSystem& out);  // blocking copy of the particle state back to the host
+    // blocking copy of the nine gas meshes (density, momentum x/y/z, energy, pressure,
+    // velocity x/y/z; MESH_SIZE^3 each); empty without USE_HYDRO
+    void download_gas(std::vector<double> (&out)[9]);
 
     double current_dt = 0.0;
     long cycle_count = 0;
@@ -35,14 +43,20 @@ class DeviceEngine {
     double max_accel_sq = 1e-9;
     double pp_ms = 0.0;                  // accumulated device time of the PP force calls
     double pm_ms = 0.0;                  // accumulated device time of the mesh force calls
+    double gas_ms = 0.0;                 // accumulated device time of the gas solver and its kicks
 
    private:
-    void compute_accelerations();        // src/integrator.cpp:236-269 for dark matter alone
+    void compute_accelerations();        // src/integrator.cpp:236-269
+    double next_timestep();              // src/engine.cpp:16-22, :47-51
     double gravity_timestep() const;     // src/particles.cpp:386-391
+    nbgas_state gas_state() const;
     Config config_;
-    std::size_t n_ = 0;
+    std::size_t n_ = 0, cells_ = 0;
     double* dev_[10] = {};               // x y z vx vy vz ax ay az m
+    double* gas_[9] = {};                // GasGrid's meshes, in nbgas_state order
+    double* mesh_[5] = {};               // dm density, total density, gravity x y z
     bool stop_requested_ = false;
+    void* ev_[4] = {};                   // hipEvent_t: mesh begin/end, gas begin/end
 };
 
 }  // namespace nbh

@@ -11,6 +11,7 @@
 //   nbody_host_tests run <ini> <cycles>    ICs + device-resident engine for <cycles> steps
 //   nbody_host_tests engine <in.bin> <out.bin> <steps> <dt> <ini>
 //                                          the same steps with the state resident on the GPU
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -174,6 +175,7 @@ static int run_kdk(const char* in_path, const char* out_path, int steps, double 
                    bool device_resident) {
     Config config;
     config.load(ini);
+    config.USE_HYDRO = false;   // the particle file carries no gas: dark matter only
     config.MAX_CYCLES = steps;
     config.USE_ADAPTIVE_DT = !(dt > 0.0);
     if (dt > 0.0) config.FIXED_DT = dt;
@@ -251,14 +253,36 @@ int main(int argc, char** argv) {
             config.load(argv[2]);
             config.MAX_CYCLES = std::atoi(argv[3]);
             Cosmology cosmo;
-            ParticleSystem dm = initialize_particles(config, cosmo);
-            DeviceEngine engine(config, dm);
-            std::printf("cycle 0: a=%.6f dt=%.6e max|a|^2=%.6e\n", engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq);
+            ZeldovichField field;
+            ParticleSystem dm = initialize_particles(config, cosmo, &field);
+            DeviceEngine engine(config, dm, config.USE_HYDRO ? &field : nullptr);
+            auto report = [&](const char* when) {
+                ParticleSystem now(config);
+                engine.download(now);
+                std::printf("%s: cycle %ld a=%.17g dt=%.17g max|a|^2=%.17g\n", when, engine.cycle_count,
+                            engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq);
+                if (now.num_particles)
+                    std::printf("%s: p0 acc %.17g %.17g %.17g\n", when, now.acc_x[0], now.acc_y[0], now.acc_z[0]);
+                std::vector<double> gas[9];
+                engine.download_gas(gas);
+                if (!gas[0].empty()) {
+                    double mass = 0.0, energy = 0.0;
+                    for (double v : gas[0]) mass += v;
+                    for (double v : gas[4]) energy += v;
+                    std::printf("%s: gas mass %.17g energy %.17g\n", when, mass * config.CELL_VOLUME,
+                                energy * config.CELL_VOLUME);
+                }
+            };
+            report("initial");
+            const auto t0 = std::chrono::steady_clock::now();
             const ExitStatus st = engine.run();
-            std::printf("cycle %ld: a=%.6f dt=%.6e max|a|^2=%.6e  PP %.3f ms/cycle  mesh %.3f ms/cycle  exit=%d\n",
-                        engine.cycle_count, engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq,
+            const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            report("final");
+            std::printf("timing: %ld cycles, %.3f ms/cycle wall; PP %.3f, mesh %.3f, hydro sweeps %.3f ms/cycle (device); exit=%d\n",
+                        engine.cycle_count, wall_ms / std::max(1L, engine.cycle_count),
                         engine.pp_ms / (engine.cycle_count + 1), engine.pm_ms / (engine.cycle_count + 1),
-                        static_cast<int>(st));
+                        engine.gas_ms / std::max(1L, engine.cycle_count), static_cast<int>(st));
+            nbgas_shutdown();
             nbpm_shutdown();
             nbpp_shutdown();
             return 0;

@@ -1,5 +1,7 @@
 #include "ics.hpp"
 
+#include <utility>
+
 #include <hip/hip_runtime_api.h>
 #include <hipfft/hipfft.h>
 
@@ -173,13 +175,25 @@ void initialize_dm(ParticleSystem& dm, const Cosmology& cosmo, const Config& con
             }
 }
 
-ParticleSystem initialize_particles(const Config& config, Cosmology& cosmo) {
+ParticleSystem initialize_particles(const Config& config, Cosmology& cosmo, ZeldovichField* field_out) {
     cosmo.total_time = 0.0;                                                          // :292-293
     update_cosmology(cosmo, config);
-    const ZeldovichField zf = compute_zeldovich_field(cosmo.scale_factor, config);   // :295-296
+    ZeldovichField zf = compute_zeldovich_field(cosmo.scale_factor, config);         // :295-296
     ParticleSystem dm(config);
     initialize_dm(dm, cosmo, config, zf);                                            // :299
+    if (field_out) *field_out = std::move(zf);
     return dm;
+}
+
+double internal_energy_from_temperature(double T_kelvin, double hubble_param, double box_size_mpc,
+                                        double domain_size, double gamma) {
+    const double k_B = 1.380649e-23, m_p = 1.67262192e-27, mu = 1.22;
+    const double u_physical_m2_s2 = (k_B * T_kelvin) / ((gamma - 1.0) * mu * m_p);
+    const double H0 = hubble_param * 100.0;
+    const double code_unit_mpc = box_size_mpc / domain_size;
+    const double V_unit_km_s = 1.5 * H0 * code_unit_mpc;
+    const double V_unit_m_s = V_unit_km_s * 1000.0;
+    return u_physical_m2_s2 / (V_unit_m_s * V_unit_m_s);
 }
 
 }  // namespace nbh

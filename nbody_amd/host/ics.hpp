@@ -24,7 +24,12 @@ void initialize_dm(ParticleSystem& dm, const Cosmology& cosmo, const Config& con
                    const ZeldovichField& zf);
 
 // The dark-matter part of initialize_state (src/ics.cpp:290-300): cosmology at t = 0, field,
-// particles.  Accelerations are left at zero; the engine computes them.
-ParticleSystem initialize_particles(const Config& config, Cosmology& cosmo);
+// particles.  Accelerations are left at zero; the engine computes them.  `field_out`, if given,
+// receives the displacement field, which the gas's initial state also needs (:302-303).
+ParticleSystem initialize_particles(const Config& config, Cosmology& cosmo, ZeldovichField* field_out = nullptr);
+
+// get_internal_energy_from_temp_k (src/ics.cpp:218-239): specific internal energy in code units.
+double internal_energy_from_temperature(double T_kelvin, double hubble_param, double box_size_mpc,
+                                        double domain_size, double gamma);
 
 }  // namespace nbh
