@@ -87,10 +87,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # Rehearsal of the multi-rank flow on a box with ONE GPU (never what the scaling numbers come
+    # from): NBODY_BENCH_ONE_DEVICE=1 puts every rank on device 0 and uses gloo, since RCCL does
+    # not accept two ranks on one device.
+    rehearsal = os.environ.get("NBODY_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     lib = nbody_amd.load(device=local_rank)
     lib.set_option(ffi.OPT_TIMING, 1)
@@ -219,7 +228,8 @@ def main():
             "metric": "pair interactions/sec", "value": value, "unit": "Ginter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" + (" (REHEARSAL: all ranks share one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": workload, "n_particles": n, "parallelism": f"i-partition x{world}",
                        "flops_per_interaction": flops,
                        "kernel": kernel_names.get(st.get("kernel_variant"), "?"),
