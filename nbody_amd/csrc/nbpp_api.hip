@@ -86,13 +86,14 @@ struct Ctx {
     Buf host_in[4], host_acc[3];      // staging for the host-pointer entry point
     Buf canon[3];                     // P3M: positions brought into [0, L)
     Buf blockmax, counter, massinfo;
+    Buf biglist;                      // cells too full for the one-thread sort: count, ids
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
             opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0;
     nbpp_stats stats{};
     void release() {
         for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
                        &host_in[1], &host_in[2], &host_in[3], &host_acc[0], &host_acc[1],
-                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter, &massinfo})
+                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter, &massinfo, &biglist})
             b->release();
         src.release();
         tgt.release();
@@ -136,6 +137,18 @@ PairConsts make_consts(const nbpp_params* p) {
     return k;
 }
 
+// Members of every cell into ascending entry order (k_cell_canon, k_cell_canon_big).
+int canonical_order(int ncell, int n_entries, const int* start, int* order, int* tmp_val, int* tmp_rank,
+                    hipStream_t s) {
+    CHK(g.biglist.ensure(sizeof(int) * (static_cast<size_t>(n_entries) / CANON_SMALL + 2)));
+    int* big = g.biglist.as<int>();
+    HIPCHK(hipMemsetAsync(big, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s, ncell, start, order, big);
+    hipLaunchKernelGGL(k_cell_canon_big, dim3(1024), dim3(WG), 0, s, start, order, big, tmp_val, tmp_rank);
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
 // Exclusive scan of count[0..n) into start[0..n); n includes the trailing zero entry, so
 // start[n-1] is the grand total.
 int exclusive_scan(int n, const int* count, int* start, hipStream_t s) {
@@ -166,9 +179,9 @@ int sort_by_cell(int n, const double* x, const double* y, const double* z, const
     CHK(exclusive_scan(static_cast<int>(ncell + 1), g.count.as<int>(), out.start.as<int>(), s));
     hipLaunchKernelGGL(k_bin_scatter, dim3(cdiv(n, WG)), dim3(WG), 0, s, n, out.cell.as<int>(),
                        out.rank.as<int>(), out.start.as<int>(), out.order.as<int>());
-    hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s,
-                       static_cast<int>(ncell), out.start.as<int>(), out.order.as<int>());
-    HIPCHK(hipGetLastError());
+    // cell / rank have done their job in the scatter: scratch for the sort of over-full cells
+    CHK(canonical_order(static_cast<int>(ncell), n, out.start.as<int>(), out.order.as<int>(),
+                        out.cell.as<int>(), out.rank.as<int>(), s));
     out.n = n;
     return NBPP_OK;
 }
@@ -409,8 +422,10 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
     hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
                        start, count, entries);
-    hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s, static_cast<int>(ncell),
-                       start, entries);
+    CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));   // scratch here, target flags / slots below
+    CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
+    CHK(canonical_order(static_cast<int>(ncell), n_entries, start, entries, g.src.cell.as<int>(),
+                        g.src.rank.as<int>(), s));
     hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries,
                        cx, cy, cz, m, p->G, p->domain_size, rec, frec);
 

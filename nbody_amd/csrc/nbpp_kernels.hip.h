@@ -256,10 +256,21 @@ __global__ void k_bin_scatter(int n, const int* __restrict__ cell, const int* __
 
 // The atomic ranks above depend on arrival order; putting each cell's members in
 // ascending original index makes the sorted order a pure function of the input.
-__global__ void k_cell_canon(int ncell, const int* __restrict__ start, int* __restrict__ order) {
+// One thread sorts one cell by insertion, which is right for the few members a cell normally
+// has.  A cell with more than CANON_SMALL members (the core of a collapsed halo holds thousands)
+// is put on a list instead and sorted by a whole workgroup in k_cell_canon_big: by insertion its
+// one thread would need O(members^2) steps while the rest of the GPU waits.
+constexpr int CANON_SMALL = 48;
+
+__global__ void k_cell_canon(int ncell, const int* __restrict__ start, int* __restrict__ order,
+                             int* __restrict__ big) {   // big[0] = count, big[1..] = cell ids
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
     const int b = start[c], e = start[c + 1];
+    if (e - b > CANON_SMALL) {
+        big[1 + atomicAdd(&big[0], 1)] = c;
+        return;
+    }
     for (int p = b + 1; p < e; ++p) {
         const int v = order[p];
         int q = p - 1;
@@ -268,6 +279,39 @@ __global__ void k_cell_canon(int ncell, const int* __restrict__ start, int* __re
             --q;
         }
         order[q + 1] = v;
+    }
+}
+
+// Rank sort of the listed cells, one workgroup per cell at a time: the rank of a member is the
+// number of members with a smaller entry (entries are distinct).  tmp_val / tmp_rank: scratch
+// as long as `order`.
+__global__ void __launch_bounds__(WG) k_cell_canon_big(const int* __restrict__ start, int* __restrict__ order,
+                                                       const int* __restrict__ big, int* __restrict__ tmp_val,
+                                                       int* __restrict__ tmp_rank) {
+    __shared__ int tile[1024];
+    const int n_big = big[0];
+    for (int k = blockIdx.x; k < n_big; k += gridDim.x) {
+        const int c = big[1 + k];
+        const int b = start[c], e = start[c + 1];
+        // every thread walks the same number of rounds so that the barriers inside line up
+        const int rounds = (e - b + WG - 1) / WG;
+        for (int r = 0; r < rounds; ++r) {
+            const int p = b + r * WG + threadIdx.x;
+            const int v = p < e ? order[p] : 0;
+            int rank = 0;
+            for (int t0 = b; t0 < e; t0 += 1024) {          // members staged through LDS, 1024 at a time
+                const int len = min(1024, e - t0);
+                __syncthreads();
+                for (int u = threadIdx.x; u < len; u += WG) tile[u] = order[t0 + u];
+                __syncthreads();
+                if (p < e)
+                    for (int u = 0; u < len; ++u) rank += tile[u] < v ? 1 : 0;
+            }
+            if (p < e) { tmp_val[p] = v; tmp_rank[p] = rank; }
+        }
+        __syncthreads();
+        for (int p = b + threadIdx.x; p < e; p += WG) order[b + tmp_rank[p]] = tmp_val[p];
+        __syncthreads();
     }
 }
 
@@ -691,7 +735,7 @@ __global__ void k_ghost_count(int n, const double* __restrict__ x, const double*
 }
 
 // `fill` starts at zero; the within-cell order produced here is arbitrary and is made
-// deterministic by k_cell_canon afterwards.
+// deterministic by k_cell_canon / k_cell_canon_big afterwards.
 __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const double* __restrict__ y,
                                 const double* __restrict__ z, GhostGrid g,
                                 const int* __restrict__ start, int* __restrict__ fill,

@@ -275,7 +275,21 @@ int main(int argc, char** argv) {
             };
             report("initial");
             const auto t0 = std::chrono::steady_clock::now();
-            const ExitStatus st = engine.run();
+            // engine.run() (src/engine.cpp:78-91) unrolled, to log like the reference does every
+            // DEBUG_INFO_EVERY_CYCLES cycles (src/engine.cpp:69-75)
+            while (engine.needs_more_cycles) {
+                engine.step();
+                if (config.DEBUG_INFO_EVERY_CYCLES > 0 && engine.cycle_count % config.DEBUG_INFO_EVERY_CYCLES == 0) {
+                    nbpp_stats ps{};
+                    nbpp_get_stats(&ps);
+                    std::printf("cycle %ld: a=%.6f dt=%.4e max|a|^2=%.4e | last PP call %.3f ms (binning %.3f, pairs %.3f), %.4g accepted pairs (%.1f G/s)\n",
+                                engine.cycle_count, engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq,
+                                ps.total_ms, ps.prepare_ms, ps.pair_kernel_ms, static_cast<double>(ps.pairs_accepted),
+                                ps.total_ms > 0 ? ps.pairs_accepted / ps.total_ms * 1e-6 : 0.0);
+                }
+            }
+            const ExitStatus st = engine.cycle_count >= config.MAX_CYCLES ? ExitStatus::ReachedMaxCycles
+                                                                          : ExitStatus::ReachedMaxScaleFactor;
             const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             report("final");
             std::printf("timing: %ld cycles, %.3f ms/cycle wall; PP %.3f, mesh %.3f, hydro sweeps %.3f ms/cycle (device); exit=%d\n",

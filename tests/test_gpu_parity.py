@@ -535,3 +535,24 @@ def test_p3m_extreme_clustering(lib, oracle):
     assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
     assert normalised_error(got, want) < TOL
     assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
+
+
+@pytest.mark.parametrize("use_pm", [False, True])
+def test_overfull_cells_are_ordered_deterministically(lib, use_pm):
+    """Cells with thousands of members take the workgroup sort instead of the one-thread
+    insertion sort; the sorted order, and with it every sum of the ordered kernels, must still be
+    a pure function of the input: two evaluations agree bit for bit."""
+    rng = np.random.default_rng(77)
+    pts = np.concatenate([0.21 + 1e-3 * rng.random((5000, 3)), 0.8 + 3e-3 * rng.random((2500, 3)),
+                          rng.random((9000, 3))])
+    pos = [np.ascontiguousarray(pts[:, c]) for c in range(3)]
+    m = datasets.masses(pts.shape[0], equal=False)
+    p = Config(MESH_SIZE=32, N_PER_SIDE=25, USE_PM=use_pm).pp_params()
+    lib.set_option(ffi.OPT_DETERMINISTIC, 1)
+    try:
+        a = gpu_acc(lib, p, pos, m)
+        b = gpu_acc(lib, p, pos, m)
+    finally:
+        lib.set_option(ffi.OPT_DETERMINISTIC, 0)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
