@@ -286,6 +286,7 @@ int main(int argc, char** argv) {
                                 engine.cycle_count, engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq,
                                 ps.total_ms, ps.prepare_ms, ps.pair_kernel_ms, static_cast<double>(ps.pairs_accepted),
                                 ps.total_ms > 0 ? ps.pairs_accepted / ps.total_ms * 1e-6 : 0.0);
+                    std::fflush(stdout);
                 }
             }
             const ExitStatus st = engine.cycle_count >= config.MAX_CYCLES ? ExitStatus::ReachedMaxCycles
