@@ -214,7 +214,7 @@ def test_direct_box_sizes(lib, oracle, L):
 
 
 def test_direct_32cubed_full(lib, oracle):
-    """BASELINE config 1 size: 32^3 particles, PP only, every ordered pair."""
+    """32^3 particles (the reference's CPU-runnable size), PP only, every ordered pair."""
     pos = datasets.jittered_lattice(32)
     m = datasets.masses(32768)
     p = Config(MESH_SIZE=32, N_PER_SIDE=32, USE_PM=False).pp_params()
@@ -422,7 +422,7 @@ def test_kick_drift_max_exact(lib, oracle):
 
 
 # --------------------------------------------------------------------------------------
-# full-size properties (BASELINE config 2 size, sampled)
+# full-size properties (the 128^3 headline size, sampled)
 # --------------------------------------------------------------------------------------
 def test_128cubed_sampled_targets_and_momentum(lib, oracle):
     """N = 128^3 direct sum on the GPU: 48 sampled targets against the oracle's exact sum over
