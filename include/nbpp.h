@@ -104,8 +104,10 @@ enum {
                                     0 = automatic                                        */
     NBPP_OPT_NO_EQUAL_MASS_PATH = 6, /* 1 = always multiply by the source mass per pair, even
                                     when all masses are equal (testing)                  */
-    NBPP_OPT_DETERMINISTIC = 7   /* 1 = never pick NBPP_KERNEL_DIRECT_SYMMETRIC by itself:
+    NBPP_OPT_DETERMINISTIC = 7,  /* 1 = never pick NBPP_KERNEL_DIRECT_SYMMETRIC by itself:
                                     results are then bitwise reproducible from run to run */
+    NBPP_OPT_P3M_LANES_PER_TARGET = 8 /* P3M cell kernel: 0 = automatic (more lanes the fewer
+                                    targets), else 1, 2, 4 or 8                           */
 };
 
 /*

@@ -88,7 +88,7 @@ struct Ctx {
     Buf blockmax, counter, massinfo;
     Buf biglist;                      // cells too full for the one-thread sort: count, ids
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0;
+            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0;
     nbpp_stats stats{};
     void release() {
         for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
@@ -455,14 +455,28 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     a.accepted = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
     a.k = k;
     const bool wide = n_entries >= (1 << 27);   // 32-byte records beyond 32-bit byte offsets
-    const dim3 grid_dim(cdiv(n_tgt, WG)), wg_dim(WG);
-    if (p->soft_sq == 0.0) {
-        if (wide) hipLaunchKernelGGL((k_p3m_cells<true, true>), grid_dim, wg_dim, 0, s, a);
-        else      hipLaunchKernelGGL((k_p3m_cells<true, false>), grid_dim, wg_dim, 0, s, a);
-    } else {
-        if (wide) hipLaunchKernelGGL((k_p3m_cells<false, true>), grid_dim, wg_dim, 0, s, a);
-        else      hipLaunchKernelGGL((k_p3m_cells<false, false>), grid_dim, wg_dim, 0, s, a);
+    // lanes per target: enough lanes for every SIMD to hold several wavefronts
+    int lanes = 1;
+    while (lanes < 8 && static_cast<long long>(n_tgt) * lanes < 400000) lanes *= 2;
+    if (g.opt_p3m_lanes == 1 || g.opt_p3m_lanes == 2 || g.opt_p3m_lanes == 4 || g.opt_p3m_lanes == 8)
+        lanes = static_cast<int>(g.opt_p3m_lanes);
+    const dim3 grid_dim(cdiv(static_cast<long long>(n_tgt) * lanes, WG)), wg_dim(WG);
+    const bool soft0 = p->soft_sq == 0.0;
+#define NBPP_LAUNCH_P3M(S0, W, L) hipLaunchKernelGGL((k_p3m_cells<S0, W, L>), grid_dim, wg_dim, 0, s, a)
+#define NBPP_P3M_LANES(S0, W)                                       \
+    switch (lanes) {                                                \
+        case 1: NBPP_LAUNCH_P3M(S0, W, 1); break;                   \
+        case 2: NBPP_LAUNCH_P3M(S0, W, 2); break;                   \
+        case 4: NBPP_LAUNCH_P3M(S0, W, 4); break;                   \
+        default: NBPP_LAUNCH_P3M(S0, W, 8); break;                  \
     }
+    if (soft0) {
+        if (wide) { NBPP_P3M_LANES(true, true) } else { NBPP_P3M_LANES(true, false) }
+    } else {
+        if (wide) { NBPP_P3M_LANES(false, true) } else { NBPP_P3M_LANES(false, false) }
+    }
+#undef NBPP_P3M_LANES
+#undef NBPP_LAUNCH_P3M
     HIPCHK(hipGetLastError());
     g.stats.pairs_evaluated = 0;  // candidates depend on the data; see pairs_accepted
     g.stats.pair_launches = 1;
@@ -582,6 +596,7 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_P3M_SEARCH_RADIUS: g.opt_p3m_radius = value; return NBPP_OK;
         case NBPP_OPT_NO_EQUAL_MASS_PATH: g.opt_no_uniform = value; return NBPP_OK;
         case NBPP_OPT_DETERMINISTIC: g.opt_deterministic = value; return NBPP_OK;
+        case NBPP_OPT_P3M_LANES_PER_TARGET: g.opt_p3m_lanes = value; return NBPP_OK;
         default: return fail(NBPP_ERR_ARG, "unknown option key %d", key);
     }
 }

@@ -888,10 +888,14 @@ __device__ __forceinline__ double4 load_record_checked(__amdgpu_buffer_rsrc_t rs
     return make_double4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <bool SOFT0, bool WIDE>
+// S (1, 2, 4 or 8) lanes share one target, lane `sub` taking rows sub, sub + S, ...; their sums
+// are added in a fixed order at the end.  One lane per target cannot fill the GPU below a few
+// hundred thousand targets (the reference's shipped run has 32768).
+template <bool SOFT0, bool WIDE, int S>
 __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
     __shared__ int queue[P3M_QCAP][WG];
-    const int t = blockIdx.x * WG + threadIdx.x;
+    const int gt = blockIdx.x * WG + threadIdx.x;
+    const int t = gt / S, sub = gt % S;
     const bool live = t < a.n_tgt;
     const int p = a.tlist[live ? t : a.n_tgt - 1];
     const double4 me = a.rec[p];
@@ -945,16 +949,33 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
         cnt -= taken;
     };
 
-    // Rows (ox, oy) in [-R, R]^2, oy fastest; the wavefront walks them together.  `base` is the
-    // padded id of the middle cell of the row whose bounds are in flight into (nj, nje): they
-    // are requested when the row before is entered.
+    // Rows (ox, oy) in [-R, R]^2, oy fastest; the wavefront walks them together (S = 1) or S at a
+    // time, one per lane of a target (S > 1).  `base` is the padded id of the middle cell of the
+    // row whose bounds are in flight into (nj, nje): they are requested when the row before is
+    // entered.
     const int span = 2 * g.R + 1;
     const int n_rows = span * span;
+    const int n_rounds = (n_rows + S - 1) / S;
     const int row_jump = g.np * (g.np - span + 1);   // last row of one ox to the first of the next
-    int base = ((pcx - g.R) * g.np + (pcy - g.R)) * g.np + pcz;
-    int row = 0, oy = 0;   // rows entered so far; wave-uniform
+    int base = ((pcx - g.R) * g.np + (pcy - g.R)) * g.np + pcz;   // row 0
+    int round = 0, oy = 0;   // rounds entered so far; wave-uniform
     int j = 0, je = 0;
-    int nj = load_word(a.cell_start, base - g.R), nje = load_word(a.cell_start, base + g.R + 1);
+    int nj = 0, nje = 0;
+    // bounds of this lane's row of round `r` (S > 1): row index r * S + sub, none past the end
+    auto request_bounds = [&](int r) {
+        const int my_row = r * S + sub;
+        const int ox = my_row / span, oyy = my_row - ox * span;
+        const int b = ((pcx - g.R + ox) * g.np + (pcy - g.R + oyy)) * g.np + pcz;
+        const bool has = my_row < n_rows;
+        nj = has ? load_word(a.cell_start, b - g.R) : 0;
+        nje = has ? load_word(a.cell_start, b + g.R + 1) : 0;
+    };
+    if constexpr (S == 1) {
+        nj = load_word(a.cell_start, base - g.R);
+        nje = load_word(a.cell_start, base + g.R + 1);
+    } else {
+        request_bounds(0);
+    }
     bool done = false;
 #pragma unroll 1
     while (!done) {
@@ -962,15 +983,19 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
         // not touch the sums, so they stay in their registers across it.
 #pragma unroll 1
         for (;;) {
-            if (!__any(j < je)) {   // every lane has finished its run: enter the next row
-                if (row == n_rows) { done = true; break; }
+            if (!__any(j < je)) {   // every lane has finished its run: enter the next round of rows
+                if (round == n_rounds) { done = true; break; }
                 j = nj; je = nje;
-                ++row;
-                const bool wrap = oy + 1 == span;
-                base += (row < n_rows) ? (wrap ? row_jump : g.np) : 0;   // after the last row: itself again
-                oy = wrap ? 0 : oy + 1;
-                nj = load_word(a.cell_start, base - g.R);
-                nje = load_word(a.cell_start, base + g.R + 1);
+                ++round;
+                if constexpr (S == 1) {
+                    const bool wrap = oy + 1 == span;
+                    base += (round < n_rows) ? (wrap ? row_jump : g.np) : 0;   // after the last row: itself again
+                    oy = wrap ? 0 : oy + 1;
+                    nj = load_word(a.cell_start, base - g.R);
+                    nje = load_word(a.cell_start, base + g.R + 1);
+                } else {
+                    request_bounds(round);
+                }
             }
             // two candidates per lane per trip; an exhausted lane fetches nothing and is rejected
             const bool v0 = j < je, v1 = j + 1 < je;
@@ -1002,7 +1027,14 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
         drain(done ? P3M_QCAP : P3M_DRAIN);
     }
 
-    if (live) {
+    // the S lanes of a target sit next to each other: fixed-order tree sum
+#pragma unroll
+    for (int d = 1; d < S; d <<= 1) {
+        ax += __shfl_xor(ax, d, 64);
+        ay += __shfl_xor(ay, d, 64);
+        az += __shfl_xor(az, d, 64);
+    }
+    if (live && sub == 0) {
         const int o = static_cast<int>(static_cast<unsigned>(a.entries[p]) & GHOST_INDEX_MASK) - a.tgt_begin;
         a.ax[o] += ax; a.ay[o] += ay; a.az[o] += az;
     }

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NBPP_LIB") or os.path.join(HERE, "lib", "libnbpp.so")
 KERNEL_NONE, KERNEL_DIRECT, KERNEL_DIRECT_WRAP, KERNEL_P3M_CELLS, KERNEL_P3M_ALLPAIRS, \
     KERNEL_DIRECT_SYMMETRIC = range(6)
 OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SEARCH_RADIUS, \
-    OPT_NO_EQUAL_MASS_PATH, OPT_DETERMINISTIC = 1, 2, 3, 4, 5, 6, 7
+    OPT_NO_EQUAL_MASS_PATH, OPT_DETERMINISTIC, OPT_P3M_LANES_PER_TARGET = 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = (
     "nbpp_init", "nbpp_shutdown", "nbpp_last_error", "nbpp_set_option", "nbpp_get_stats",

@@ -556,3 +556,28 @@ def test_overfull_cells_are_ordered_deterministically(lib, use_pm):
         lib.set_option(ffi.OPT_DETERMINISTIC, 0)
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+def test_p3m_lanes_per_target(lib, oracle, lanes):
+    """The cell kernel with 1, 2, 4 or 8 lanes sharing a target (automatic choice: more lanes the
+    fewer targets): same accepted pairs, same forces, and a sub-range of targets."""
+    pos = datasets.clustered(20000, seed=lanes)
+    m = datasets.masses(20000, equal=False)
+    p = Config(MESH_SIZE=32, N_PER_SIDE=27, USE_PM=True).pp_params()
+    want = oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS)
+    lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, lanes)
+    try:
+        got = gpu_acc(lib, p, pos, m)
+        assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
+        assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
+        assert normalised_error(got, want) < TOL
+        import torch
+        d = [torch.as_tensor(a, device="cuda:0") for a in pos + [m]]
+        part = [torch.zeros(5001, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+        lib.accumulate_device(p, *d, *part, tgt_begin=7003, n_tgt=5001)
+        torch.cuda.synchronize()
+        sub = [w[7003:7003 + 5001] for w in want]
+        assert normalised_error([t.cpu().numpy() for t in part], sub) < TOL
+    finally:
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
