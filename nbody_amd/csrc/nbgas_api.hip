@@ -17,54 +17,19 @@
 #include <mutex>
 
 #include "../../include/nbgas.h"
+#include "nb_common.hip.h"
 
 namespace {
+
+static_assert(NBGAS_OK == nbc::OK && NBGAS_ERR_ARG == nbc::ERR_ARG && NBGAS_ERR_HIP == nbc::ERR_HIP &&
+              NBGAS_ERR_NOINIT == nbc::ERR_NOINIT && NBGAS_ERR_NOMEM == nbc::ERR_NOMEM, "error codes");
 
 constexpr int WG = 256;
 constexpr double FLOOR = 1e-12;
 
-thread_local char g_err[512] = "";
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(NBGAS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-#define CHK(expr)                        \
-    do {                                 \
-        int rc_ = (expr);                \
-        if (rc_ != NBGAS_OK) return rc_; \
-    } while (0)
-
-struct Buf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return NBGAS_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(NBGAS_ERR_NOMEM, "hipMalloc of %zu bytes failed", bytes);
-        }
-        cap = bytes;
-        return NBGAS_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
+using nbc::Buf;
+using nbc::cdiv;
+using nbc::fail;
 
 struct Ctx {
     bool ready = false;
@@ -74,8 +39,6 @@ struct Ctx {
 };
 Ctx g;
 std::mutex g_mu;
-
-inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 
 // ---- one cell --------------------------------------------------------------------------
 struct Conserved { double rho, m[3], en; };
@@ -331,7 +294,7 @@ void nbgas_shutdown(void) {
     g.device = -1;
 }
 
-const char* nbgas_last_error(void) { return g_err; }
+const char* nbgas_last_error(void) { return nbc::error_text(); }
 
 int nbgas_update_primitives_device(const nbgas_params* p, const nbgas_state* s, void* stream) {
     ENTER();

@@ -20,60 +20,26 @@
 #include <mutex>
 
 #include "../../include/nbpm.h"
+#include "nb_common.hip.h"
 
 namespace {
+
+static_assert(NBPM_OK == nbc::OK && NBPM_ERR_ARG == nbc::ERR_ARG && NBPM_ERR_HIP == nbc::ERR_HIP &&
+              NBPM_ERR_NOINIT == nbc::ERR_NOINIT && NBPM_ERR_NOMEM == nbc::ERR_NOMEM, "error codes");
 
 constexpr int WG = 256;
 constexpr double PI = 3.14159265358979323846;   // M_PI
 
-thread_local char g_err[512] = "";
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(NBPM_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+using nbc::Buf;
+using nbc::cdiv;
+using nbc::fail;
+
 #define FFTCHK(expr)                                                                          \
     do {                                                                                      \
         hipfftResult r_ = (expr);                                                             \
         if (r_ != HIPFFT_SUCCESS)                                                             \
             return fail(NBPM_ERR_HIP, "%s: hipfftResult %d (%s:%d)", #expr, (int)r_, __FILE__, __LINE__); \
     } while (0)
-#define CHK(expr)                  \
-    do {                           \
-        int rc_ = (expr);          \
-        if (rc_ != NBPM_OK) return rc_; \
-    } while (0)
-
-struct Buf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return NBPM_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(NBPM_ERR_NOMEM, "hipMalloc of %zu bytes failed", bytes);
-        }
-        cap = bytes;
-        return NBPM_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
 
 struct Ctx {
     bool ready = false;
@@ -89,8 +55,6 @@ struct Ctx {
 };
 Ctx g;
 std::mutex g_mu;
-
-inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 
 // ---- cloud-in-cell geometry of one particle: src/particles.cpp:60-83 / :112-114 ----
 struct Cloud {
@@ -370,7 +334,7 @@ void nbpm_shutdown(void) {
     g.device = -1;
 }
 
-const char* nbpm_last_error(void) { return g_err; }
+const char* nbpm_last_error(void) { return nbc::error_text(); }
 
 int nbpm_set_timing(int on) {
     std::lock_guard<std::mutex> lock(g_mu);
