@@ -274,6 +274,36 @@ int main(int argc, char** argv) {
                 }
             };
             report("initial");
+            // Snapshots with the reference's cadence (src/engine.cpp:28-33, :56-67): one at the start,
+            // one whenever a passes next_output_a, one at the end.  Raw little-endian doubles, not
+            // HDF5: {n, mesh, a, t, L, use_hydro}, x, y, z, mass[n], then gas density and energy
+            // [mesh^3] with hydro.
+            const char* snap_prefix = argc >= 5 ? argv[4] : nullptr;
+            int snapshot_count = 0;
+            double next_output_a = config.START_A + config.SAVE_HDF5_EVERY_DELTA_A;
+            auto save_snapshot = [&]() {
+                if (!snap_prefix) return;
+                ParticleSystem now(config);
+                engine.download(now);
+                std::vector<double> gas[9];
+                engine.download_gas(gas);
+                char name[1024];
+                std::snprintf(name, sizeof(name), "%s_%04d.bin", snap_prefix, snapshot_count++);
+                FILE* f = std::fopen(name, "wb");
+                if (!f) throw std::runtime_error("cannot open snapshot file");
+                const double head[6] = {static_cast<double>(now.num_particles), static_cast<double>(config.MESH_SIZE),
+                                        engine.cosmo.scale_factor, engine.cosmo.total_time, config.DOMAIN_SIZE,
+                                        config.USE_HYDRO ? 1.0 : 0.0};
+                std::fwrite(head, sizeof(double), 6, f);
+                for (auto* v : {&now.pos_x, &now.pos_y, &now.pos_z, &now.mass})
+                    std::fwrite(v->data(), sizeof(double), v->size(), f);
+                if (config.USE_HYDRO) {
+                    std::fwrite(gas[0].data(), sizeof(double), gas[0].size(), f);
+                    std::fwrite(gas[4].data(), sizeof(double), gas[4].size(), f);
+                }
+                std::fclose(f);
+            };
+            if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0) save_snapshot();
             const auto t0 = std::chrono::steady_clock::now();
             // engine.run() (src/engine.cpp:78-91) unrolled, to log like the reference does every
             // DEBUG_INFO_EVERY_CYCLES cycles (src/engine.cpp:69-75)
@@ -287,6 +317,11 @@ int main(int argc, char** argv) {
                                 ps.total_ms, ps.prepare_ms, ps.pair_kernel_ms, static_cast<double>(ps.pairs_accepted),
                                 ps.total_ms > 0 ? ps.pairs_accepted / ps.total_ms * 1e-6 : 0.0);
                     std::fflush(stdout);
+                }
+                const bool must_save = engine.cosmo.scale_factor >= next_output_a;
+                if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0 && (!engine.needs_more_cycles || must_save)) {
+                    save_snapshot();
+                    while (next_output_a <= engine.cosmo.scale_factor) next_output_a += config.SAVE_HDF5_EVERY_DELTA_A;
                 }
             }
             const ExitStatus st = engine.cycle_count >= config.MAX_CYCLES ? ExitStatus::ReachedMaxCycles
@@ -325,7 +360,7 @@ int main(int argc, char** argv) {
             nbpp_shutdown();
             return rc;
         }
-        std::printf("usage: %s config [ini] | gpu-tests | kdk <in> <out> <steps> <dt> <ini>\n", argv[0]);
+        std::printf("usage: %s config [ini] | gpu-tests | kdk <in> <out> <steps> <dt> <ini> | run <ini> <cycles> [snapshot-prefix]\n", argv[0]);
         return 64;
     } catch (const std::exception& e) {
         std::printf("error: %s\n", e.what());
