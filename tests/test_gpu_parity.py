@@ -452,6 +452,50 @@ def test_128cubed_sampled_targets_and_momentum(lib, oracle):
         assert abs(np.sum(m * got[c])) < 1e-9 * typical
 
 
+def test_p3m_256cubed_sampled_targets_counts_and_momentum(lib, oracle):
+    """N = 256^3 P3M short range with the mesh force on top (the whole force phase at the
+    headline P3M size): sampled target slices against the oracle's sum over all 16.8 M sources,
+    accepted-pair counts of the slices exactly, and zero net force on the system from either
+    part."""
+    import torch
+    n_side = 256
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side)
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    m = np.full(n, config.DM_PARTICLE_MASS)
+    p = config.pp_params()
+    x, y, z, mm = _t(pos + [m])
+    acc = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    lib.accumulate_device(p, x, y, z, mm, *acc)
+    torch.cuda.synchronize()
+    assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
+    total_accepted = lib.stats()["pairs_accepted"]
+    got = [a.cpu().numpy() for a in acc]
+    typical = float(np.mean(np.sqrt(got[0] ** 2 + got[1] ** 2 + got[2] ** 2))) * m[0] * n
+    for c in range(3):
+        assert abs(np.sum(m * got[c])) < 1e-9 * typical
+    rng = np.random.default_rng(9)
+    counted = 0
+    for begin in rng.choice(n - 16, 6, replace=False):     # six slices of 16 consecutive targets
+        begin = int(begin)
+        want = oracle.accumulate(p, *pos, m, tgt_begin=begin, n_tgt=16)   # every j, cutoff applied
+        assert normalised_error([g[begin:begin + 16] for g in got], want) < TOL
+        part = [torch.zeros(16, dtype=torch.float64, device="cuda") for _ in range(3)]
+        lib.accumulate_device(p, x, y, z, mm, *part, tgt_begin=begin, n_tgt=16)
+        torch.cuda.synchronize()
+        assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos, tgt_begin=begin, n_tgt=16)
+        counted += lib.stats()["pairs_accepted"]
+    assert 55 * n < total_accepted < 75 * n and 55 * 96 < counted < 75 * 96
+    # the mesh force on the same particles: no net force either
+    mesh = ffi.load_mesh(device=0)
+    macc = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    mesh.accelerations_device(config.mesh_params(), x, y, z, mm, *macc)
+    torch.cuda.synchronize()
+    for a in macc:
+        s_ = float((a * mm).sum().cpu())
+        assert abs(s_) < 1e-9 * float((a.abs() * mm).sum().cpu())
+
+
 # --------------------------------------------------------------------------------------
 # Zel'dovich initial conditions (the particle sets the reference actually starts from)
 # --------------------------------------------------------------------------------------
