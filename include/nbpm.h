@@ -66,6 +66,14 @@ int nbpm_solve_device(const nbpm_params* p, const double* rho, double* gx, doubl
                       double* gz, void* stream);
 
 /*
+ * Copies into `phi` (mesh_size^3, device) the potential mesh the last nbpm_solve_device (or
+ * nbpm_accelerations*) of that mesh size computed: the unnormalised inverse transform, i.e. the
+ * reference's state.phi (src/integrator.cpp:105-106), which its energy diagnostics read
+ * (src/diagnostics.cpp:93-97).
+ */
+int nbpm_potential_device(const nbpm_params* p, double* phi, void* stream);
+
+/*
  * acc[i] = cloud-in-cell interpolation of the three meshes at particle i (overwrite).
  * Replaces ParticleSystem::interpolate_cic_forces (src/particles.cpp:102-131); the weights
  * the reference caches in cic_data at assignment time are recomputed from the positions,

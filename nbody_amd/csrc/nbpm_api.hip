@@ -365,6 +365,18 @@ int nbpm_solve_device(const nbpm_params* p, const double* rho, double* gx, doubl
     return solve(p, rho, gx, gy, gz, static_cast<hipStream_t>(stream));
 }
 
+int nbpm_potential_device(const nbpm_params* p, double* phi, void* stream) {
+    ENTER();
+    CHK(check_params(p));
+    if (!phi) return fail(NBPM_ERR_ARG, "phi is NULL");
+    const size_t cells = static_cast<size_t>(p->mesh_size) * p->mesh_size * p->mesh_size;
+    if (g.plan_n != p->mesh_size || g.phi.cap < sizeof(double) * cells)
+        return fail(NBPM_ERR_ARG, "no potential of a %d^3 mesh has been computed", p->mesh_size);
+    HIPCHK(hipMemcpyAsync(phi, g.phi.p, sizeof(double) * cells, hipMemcpyDeviceToDevice,
+                          static_cast<hipStream_t>(stream)));
+    return NBPM_OK;
+}
+
 int nbpm_interpolate_device(const nbpm_params* p, size_t n, const double* x, const double* y,
                             const double* z, const double* gx, const double* gy,
                             const double* gz, double* ax, double* ay, double* az,

@@ -187,7 +187,7 @@ MESH_LIB_PATH = os.environ.get("NBPM_LIB") or os.path.join(HERE, "lib", "libnbpm
 
 MESH_EXPORTS = (
     "nbpm_init", "nbpm_shutdown", "nbpm_last_error", "nbpm_set_timing", "nbpm_get_stats",
-    "nbpm_deposit_device", "nbpm_solve_device", "nbpm_interpolate_device",
+    "nbpm_deposit_device", "nbpm_solve_device", "nbpm_potential_device", "nbpm_interpolate_device",
     "nbpm_accelerations_device", "nbpm_accelerations",
 )
 
@@ -224,6 +224,7 @@ class MeshLibrary:
         P = C.POINTER(MeshParams)
         L.nbpm_deposit_device.argtypes = [P, C.c_size_t] + [_DP] * 5 + [C.c_void_p]
         L.nbpm_solve_device.argtypes = [P] + [_DP] * 4 + [C.c_void_p]
+        L.nbpm_potential_device.argtypes = [P, _DP, C.c_void_p]
         L.nbpm_interpolate_device.argtypes = [P, C.c_size_t] + [_DP] * 9 + [C.c_void_p]
         L.nbpm_accelerations_device.argtypes = [P, C.c_size_t] + [_DP] * 7 + [C.c_void_p]
         L.nbpm_accelerations.argtypes = [P, C.c_size_t] + [_DP] * 7
@@ -261,6 +262,12 @@ class MeshLibrary:
             raise ValueError("meshes must hold mesh_size^3 values")
         self._check(self.lib.nbpm_solve_device(C.byref(p), _dev(rho), _dev(gx), _dev(gy), _dev(gz),
                                                C.c_void_p(stream or 0)))
+
+    def potential_device(self, p, phi, stream=None):
+        """Copy of the potential mesh of the last solve into the CUDA tensor `phi`."""
+        if phi.numel() != p.mesh_size ** 3:
+            raise ValueError("phi must hold mesh_size^3 values")
+        self._check(self.lib.nbpm_potential_device(C.byref(p), _dev(phi), C.c_void_p(stream or 0)))
 
     def interpolate_device(self, p, x, y, z, gx, gy, gz, ax, ay, az, stream=None):
         if min(t.numel() for t in (gx, gy, gz)) != p.mesh_size ** 3:

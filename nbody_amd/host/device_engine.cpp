@@ -137,15 +137,34 @@ double DeviceEngine::gravity_timestep() const {
     return std::sqrt(config_.SOFTENING_SQUARED) / std::sqrt(max_accel_sq) * config_.GRAVITY_DT_FACTOR;
 }
 
-double DeviceEngine::next_timestep() {
-    if (!config_.USE_ADAPTIVE_DT) return config_.FIXED_DT;
+double DeviceEngine::cfl_timestep() {
     double dt_cfl = std::numeric_limits<double>::infinity();                 // src/gas.cpp:302
     if (config_.USE_HYDRO) {
         const nbgas_params gp = config_.gas_params();
         const nbgas_state gs = gas_state();
         nbgas_check(nbgas_cfl_timestep_device(&gp, &gs, &dt_cfl, nullptr));
     }
-    return std::min({dt_cfl, gravity_timestep(), config_.FIXED_DT});
+    return dt_cfl;
+}
+
+double DeviceEngine::next_timestep() {
+    if (!config_.USE_ADAPTIVE_DT) return config_.FIXED_DT;
+    return std::min({cfl_timestep(), gravity_timestep(), config_.FIXED_DT});
+}
+
+void DeviceEngine::download_mesh_solve(std::vector<double>& total_rho, std::vector<double>& phi) {
+    total_rho.clear();
+    phi.clear();
+    if (!mesh_[0]) return;
+    hip_check(hipDeviceSynchronize(), "sync");
+    total_rho.resize(cells_);
+    phi.resize(cells_);
+    const double* source = config_.USE_HYDRO ? mesh_[1] : mesh_[0];
+    hip_check(hipMemcpy(total_rho.data(), source, sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
+    // the potential is staged through the dark-matter density mesh, which the next force phase rebuilds
+    const nbpm_params mp = config_.mesh_params();
+    nbpm_check(nbpm_potential_device(&mp, mesh_[0], nullptr));
+    hip_check(hipMemcpy(phi.data(), mesh_[0], sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
 }
 
 void DeviceEngine::step() {

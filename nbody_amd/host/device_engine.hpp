@@ -35,6 +35,11 @@ class DeviceEngine {
     // blocking copy of the nine gas meshes (density, momentum x/y/z, energy, pressure,
     // velocity x/y/z; MESH_SIZE^3 each); empty without USE_HYDRO
     void download_gas(std::vector<double> (&out)[9]);
+    // blocking copy of the source and the (unnormalised) potential of the last mesh solve, the
+    // reference's state.total_rho and state.phi; empty when no mesh solve has run
+    void download_mesh_solve(std::vector<double>& total_rho, std::vector<double>& phi);
+    double cfl_timestep();               // src/gas.cpp:301-323; +inf without USE_HYDRO
+    double gravity_timestep() const;     // src/particles.cpp:386-391
 
     double current_dt = 0.0;
     long cycle_count = 0;
@@ -48,7 +53,6 @@ class DeviceEngine {
    private:
     void compute_accelerations();        // src/integrator.cpp:236-269
     double next_timestep();              // src/engine.cpp:16-22, :47-51
-    double gravity_timestep() const;     // src/particles.cpp:386-391
     nbgas_state gas_state() const;
     Config config_;
     std::size_t n_ = 0, cells_ = 0;

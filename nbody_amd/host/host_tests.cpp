@@ -22,6 +22,7 @@
 
 #include "config.hpp"
 #include "device_engine.hpp"
+#include "diagnostics.hpp"
 #include "ics.hpp"
 #include "integrator.hpp"
 #include "particles.hpp"
@@ -304,6 +305,36 @@ int main(int argc, char** argv) {
                 std::fclose(f);
             };
             if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0) save_snapshot();
+            // diagnostics.csv in the directory given as the fifth argument, with the reference's
+            // columns and cadence (src/engine.cpp:24-26, :69-75)
+            Logger logger(argc >= 6 ? argv[5] : "/nonexistent");
+            long logged_cycle = 0;
+            double logged_ms[3] = {0.0, 0.0, 0.0};
+            auto logged_wall = std::chrono::steady_clock::now();
+            auto log_diagnostics = [&]() {
+                if (!logger.is_open()) return;
+                ParticleSystem now(config);
+                engine.download(now);
+                std::vector<double> gas[9], total_rho, phi;
+                engine.download_gas(gas);
+                engine.download_mesh_solve(total_rho, phi);
+                Diagnostics d = compute_diagnostics(config, now, gas, total_rho, phi, engine.cosmo,
+                                                    engine.cfl_timestep(), engine.gravity_timestep(), engine.current_dt);
+                d.cycle = engine.cycle_count;
+                const long cycles = engine.cycle_count - logged_cycle;
+                const auto wall_now = std::chrono::steady_clock::now();
+                if (cycles > 0) {                                    // averages since the last line
+                    d.avg_step = std::chrono::duration<double>(wall_now - logged_wall).count() / cycles;
+                    d.avg_pm = (engine.pm_ms - logged_ms[0]) * 1e-3 / cycles;
+                    d.avg_pp = (engine.pp_ms - logged_ms[1]) * 1e-3 / cycles;
+                    d.avg_hydro = (engine.gas_ms - logged_ms[2]) * 1e-3 / cycles;
+                }
+                logger.log(d);
+                logged_cycle = engine.cycle_count;
+                logged_ms[0] = engine.pm_ms; logged_ms[1] = engine.pp_ms; logged_ms[2] = engine.gas_ms;
+                logged_wall = std::chrono::steady_clock::now();
+            };
+            log_diagnostics();
             const auto t0 = std::chrono::steady_clock::now();
             // engine.run() (src/engine.cpp:78-91) unrolled, to log like the reference does every
             // DEBUG_INFO_EVERY_CYCLES cycles (src/engine.cpp:69-75)
@@ -318,6 +349,9 @@ int main(int argc, char** argv) {
                                 ps.total_ms > 0 ? ps.pairs_accepted / ps.total_ms * 1e-6 : 0.0);
                     std::fflush(stdout);
                 }
+                if (config.DEBUG_INFO_EVERY_CYCLES > 0 &&
+                    (!engine.needs_more_cycles || engine.cycle_count % config.DEBUG_INFO_EVERY_CYCLES == 0))
+                    log_diagnostics();
                 const bool must_save = engine.cosmo.scale_factor >= next_output_a;
                 if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0 && (!engine.needs_more_cycles || must_save)) {
                     save_snapshot();
@@ -360,7 +394,7 @@ int main(int argc, char** argv) {
             nbpp_shutdown();
             return rc;
         }
-        std::printf("usage: %s config [ini] | gpu-tests | kdk <in> <out> <steps> <dt> <ini> | run <ini> <cycles> [snapshot-prefix]\n", argv[0]);
+        std::printf("usage: %s config [ini] | gpu-tests | kdk <in> <out> <steps> <dt> <ini> | run <ini> <cycles> [snapshot-prefix [log-dir]]\n", argv[0]);
         return 64;
     } catch (const std::exception& e) {
         std::printf("error: %s\n", e.what());

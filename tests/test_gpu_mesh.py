@@ -214,3 +214,28 @@ def test_default_run_initial_accelerations_match_reference_output_on_the_gpu(lib
     for c in range(3):
         assert a[c][0] == pytest.approx(kat["p0_acc_initial_pm_plus_pp"][c], rel=1e-12)
     assert float(np.max(a[0] ** 2 + a[1] ** 2 + a[2] ** 2)) == pytest.approx(kat["max_accel_sq"], rel=1e-12)
+
+
+def test_potential_of_the_last_solve(mesh):
+    """nbpm_potential_device hands out the unnormalised inverse transform the reference keeps as
+    state.phi (src/integrator.cpp:105-106)."""
+    M, L, G = 16, 1.0, 0.3
+    rng = np.random.default_rng(1)
+    rho = rng.random((M, M, M))
+    grids = [torch.zeros(M ** 3, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    p = params(M, L, G)
+    mesh.solve_device(p, dev(rho.ravel()), *grids)
+    d_phi = torch.zeros(M ** 3, dtype=torch.float64, device="cuda:0")
+    mesh.potential_device(p, d_phi)
+    torch.cuda.synchronize()
+    phi = d_phi.cpu().numpy().reshape(M, M, M)
+    rho_k = np.fft.rfftn(rho)
+    f = np.where(np.arange(M) < M // 2, np.arange(M), np.arange(M) - M) * 2.0 * np.pi / L
+    k2 = f[:, None, None] ** 2 + f[None, :, None] ** 2 + (np.arange(M // 2 + 1) * 2.0 * np.pi / L)[None, None, :] ** 2
+    k2[0, 0, 0] = 1.0
+    phi_k = rho_k * (-4.0 * np.pi * G / k2)
+    phi_k[0, 0, 0] = 0.0
+    ref = np.fft.irfftn(phi_k, s=(M, M, M)) * M ** 3
+    assert rel_to_max(phi, ref) < TOL
+    with pytest.raises(ffi.NbppError):
+        mesh.potential_device(params(M + 1, L, G), torch.zeros((M + 1) ** 3, dtype=torch.float64, device="cuda:0"))
