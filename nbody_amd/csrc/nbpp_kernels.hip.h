@@ -9,7 +9,7 @@
 // minimum-image displacement, r^2, optional cutoff / cubic taper / subtractive
 // mesh-softened term, Plummer softening.  Algebraically the reference's
 //     a = G m / q ;  a * d / sqrt(q)         (q = r^2 + eps^2)
-// is evaluated here as d * (G m) * q^(-3/2) with q^(-3/2) from a 24-bit rsqrt seed and
+// is evaluated here as d * (G m) * q^(-3/2) with q^(-3/2) from the 24-bit v_rsq_f64 seed and
 // one third-order correction (relative error ~3e-16 per pair).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -40,23 +40,11 @@ struct PairConsts {
 };
 
 // ---------------------------------------------------------------------------------
-// q^(-3/2), q > 0 inside the f32 exponent range.
-// Seed y = rsq_f32(q) (|rel err| < 2^-22), h = 1 - q y^2, then
-//   q^(-3/2) = y^3 (1 - h)^(-3/2) = y^3 (1 + h (3/2 + 15/8 h) + O(h^3)),  |h^3| < 2^-63.
-// y has 24 significant bits, so y*y is exact in fp64.
+// q^(-3/2) from a 24-bit seed y = v_rsq_f64(q): h = 1 - q y^2, then
+//   q^(-3/2) = y^3 (1 - h)^(-3/2) = y^3 (1 + h (3/2 + 15/8 h) + O(h^3)),  |h^3| < 2^-69.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ double inv_cube_root2(double q) {
-    const float yf = __builtin_amdgcn_rsqf(static_cast<float>(q));
-    const double y = static_cast<double>(yf);
-    const double y2 = y * y;
-    const double h = __builtin_fma(-q, y2, 1.0);
-    const double y3 = y * y2;
-    const double c = h * __builtin_fma(1.875, h, 1.5);
-    return __builtin_fma(y3, c, y3);
-}
-
-// Same with the fp64 seed instruction (full exponent range) and a zero guard: used when
-// SOFTENING_SQUARED == 0, where q can be 0 for the self pair or for coincident particles.
+// With a zero guard, for SOFTENING_SQUARED == 0, where q can be 0 for the self pair or for
+// coincident particles.
 // The reference skips i == j by index (src/particles.cpp:202,302) and produces NaN for
 // two distinct coincident particles with zero softening; this returns 0 for both.
 __device__ __forceinline__ double inv_cube_root2_guarded(double q) {
@@ -1124,11 +1112,6 @@ __global__ void __launch_bounds__(WG) k_max_accel_sq(size_t n, const double* __r
 __global__ void k_fill_int(int n, int* p, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
-}
-
-__global__ void k_iota(int n, int* p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
 }
 
 }  // namespace nbpp
