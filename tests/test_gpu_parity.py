@@ -625,3 +625,48 @@ def test_p3m_lanes_per_target(lib, oracle, lanes):
         assert normalised_error([t.cpu().numpy() for t in part], sub) < TOL
     finally:
         lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_randomised_configurations(lib, oracle, seed):
+    """Seeded sweep over what a caller can vary at once: particle count (from 1 up), box length,
+    mesh size, cutoff radius and taper width, zero or default softening, equal or unequal masses,
+    particle distribution, direct or P3M mode, and a random target slice through the device
+    entry point.  Every case is compared with the oracle's exact sum and, in P3M mode, its
+    accepted-pair count."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, 1000, 2047, 2048, 2049, 4100, 6000]))
+    L = float(rng.choice([1.0, 0.5, 7.0, 100.0]))
+    mesh = int(rng.integers(4, 41))
+    use_pm = bool(rng.integers(0, 2))
+    config = Config(DOMAIN_SIZE=L, MESH_SIZE=mesh, N_PER_SIDE=max(1, round(n ** (1 / 3))), USE_PM=use_pm,
+                    CUTOFF_RADIUS_CELLS=float(rng.uniform(1.0, 4.0)),
+                    CUTOFF_TRANSITION_WIDTH_FACTOR=float(rng.uniform(0.05, 0.9)))
+    kind = int(rng.integers(0, 3))
+    if rng.random() < 0.3 and kind != 2:   # coincident particles without softening: NaN in the reference
+        config.SOFTENING_SQUARED = 0.0
+    if kind == 0:
+        pos = [c * L for c in datasets.uniform_random(n, seed=seed)]
+    elif kind == 1:
+        pos = datasets.clustered(n, L=L, seed=seed)
+    else:
+        pts = (rng.integers(0, 8, (n, 3)) + 0.5) / 8 * L           # many coincident positions
+        pos = [np.ascontiguousarray(pts[:, c]) for c in range(3)]
+    m = datasets.masses(n, equal=bool(rng.integers(0, 2)))
+    p = config.pp_params()
+    traversal = O.EXACT
+    want = oracle.accumulate(p, *pos, m, traversal=traversal)
+    got = gpu_acc(lib, p, pos, m)
+    floor = pair_force_scale(p, m, max(n, 8)) * 1e-3
+    assert normalised_error(got, want, floor=floor) < TOL
+    if lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS:   # the all-pairs fallback does not count
+        assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
+    begin = int(rng.integers(0, n))
+    count = int(rng.integers(1, n - begin + 1))
+    d = [torch.as_tensor(np.ascontiguousarray(a), device="cuda:0") for a in pos + [m]]
+    part = [torch.zeros(count, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    lib.accumulate_device(p, *d, *part, tgt_begin=begin, n_tgt=count)
+    torch.cuda.synchronize()
+    sub = [w[begin:begin + count] for w in want]
+    assert normalised_error([t.cpu().numpy() for t in part], sub, floor=floor) < TOL
