@@ -87,13 +87,14 @@ struct Ctx {
     Buf canon[3];                     // P3M: positions brought into [0, L)
     Buf blockmax, counter, massinfo;
     Buf biglist;                      // cells too full for the one-thread sort: count, ids
+    Buf ghostcode;                    // P3M: image code of every sorted entry
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
             opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0;
     nbpp_stats stats{};
     void release() {
         for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
                        &host_in[1], &host_in[2], &host_in[3], &host_acc[0], &host_acc[1],
-                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter, &massinfo, &biglist})
+                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter, &massinfo, &biglist, &ghostcode})
             b->release();
         src.release();
         tgt.release();
@@ -384,8 +385,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     const PairConsts k = make_consts(p);
     int R = 0, nside = 0;
     if (!p3m_search_grid(p, &R, &nside)) return fail(NBPP_ERR_ARG, "box too small for the cell search");
-    if (n_src > (1 << GHOST_SHIFT))
-        return fail(NBPP_ERR_RANGE, "the P3M cell kernel indexes at most 2^26 sources (got %d)", n_src);
+    if (n_src > (1 << 30))   // real + ghost entries are counted in 32-bit integers
+        return fail(NBPP_ERR_RANGE, "the P3M cell kernel takes at most 2^30 sources (got %d)", n_src);
     GhostGrid grid;
     grid.nside = nside;
     grid.R = R;
@@ -416,17 +417,19 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     CHK(g.src.order.ensure(sizeof(int) * n_entries));
     CHK(g.src.x.ensure(sizeof(double4) * n_entries));  // AoS records live in the x buffer
     int* entries = g.src.order.as<int>();
+    CHK(g.ghostcode.ensure(static_cast<size_t>(n_entries)));
+    uint8_t* codes = g.ghostcode.as<uint8_t>();
     double4* rec = g.src.x.as<double4>();
     CHK(g.src.y.ensure(sizeof(float4) * n_entries));   // and their fp32 copies in the y buffer
     float4* frec = g.src.y.as<float4>();
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
     hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
-                       start, count, entries);
+                       start, count, entries, codes);
     CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));   // scratch here, target flags / slots below
     CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
     CHK(canonical_order(static_cast<int>(ncell), n_entries, start, entries, g.src.cell.as<int>(),
                         g.src.rank.as<int>(), s));
-    hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries,
+    hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
                        cx, cy, cz, m, p->G, p->domain_size, rec, frec);
 
     // 3. compact list of targets in sorted order
@@ -436,7 +439,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     int* flag = g.src.cell.as<int>();
     int* slot = g.src.rank.as<int>();
     int* tlist = g.tgt.order.as<int>();
-    hipLaunchKernelGGL(k_target_flags, dim3(cdiv(n_entries + 1, WG)), dim3(WG), 0, s, n_entries, entries,
+    hipLaunchKernelGGL(k_target_flags, dim3(cdiv(n_entries + 1, WG)), dim3(WG), 0, s, n_entries, entries, codes,
                        tgt_begin, n_tgt, flag);
     CHK(exclusive_scan(n_entries + 1, flag, slot, s));
     hipLaunchKernelGGL(k_target_scatter, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, flag, slot,

@@ -682,11 +682,11 @@ __global__ void __launch_bounds__(WG, 4) k_pairs(const PairArgs a) {  // 4 waves
 // src/particles.cpp:94; z-fastest matches the order in which its initial conditions enumerate
 // particles, src/ics.cpp:174-187, which keeps the binning passes close to sequential.)
 //
-// Entries of the sorted array are 32-bit: original index (26 bits) | image code (2 bits per
-// axis: 0 none, 1 = +L, 2 = -L) << 26.
+// An entry of the sorted array is the particle's original index; its image code (2 bits per
+// axis: 0 none, 1 = +L, 2 = -L) sits in a byte array beside it.  All entries of one cell carry
+// the same code (it only depends on which side of the box the cell lies), so ordering a cell's
+// entries leaves the codes in place.
 // ---------------------------------------------------------------------------------
-constexpr int GHOST_SHIFT = 26;
-constexpr unsigned GHOST_INDEX_MASK = (1u << GHOST_SHIFT) - 1u;
 
 struct GhostGrid {
     double scale;   // nside / L
@@ -727,12 +727,13 @@ __global__ void k_ghost_count(int n, const double* __restrict__ x, const double*
 __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const double* __restrict__ y,
                                 const double* __restrict__ z, GhostGrid g,
                                 const int* __restrict__ start, int* __restrict__ fill,
-                                int* __restrict__ entries) {
+                                int* __restrict__ entries, uint8_t* __restrict__ codes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned code) {
         const int slot = start[cell] + atomicAdd(&fill[cell], 1);
-        entries[slot] = static_cast<int>(static_cast<unsigned>(i) | (code << GHOST_SHIFT));
+        entries[slot] = i;
+        codes[slot] = static_cast<uint8_t>(code);
     });
 }
 
@@ -741,15 +742,14 @@ __device__ __forceinline__ double image_shift(unsigned code2, double L) {
 }
 
 __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
-                               const double* __restrict__ x, const double* __restrict__ y,
+                               const uint8_t* __restrict__ codes, const double* __restrict__ x, const double* __restrict__ y,
                                const double* __restrict__ z, const double* __restrict__ m,
                                double G, double L, double4* __restrict__ rec,
                                float4* __restrict__ frec) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_entries) return;
-    const unsigned e = static_cast<unsigned>(entries[p]);
-    const int i = static_cast<int>(e & GHOST_INDEX_MASK);
-    const unsigned code = e >> GHOST_SHIFT;
+    const int i = entries[p];
+    const unsigned code = codes[p];
     const double4 r = make_double4(x[i] + image_shift(code & 3u, L), y[i] + image_shift((code >> 2) & 3u, L),
                                    z[i] + image_shift((code >> 4) & 3u, L), G * m[i]);
     rec[p] = r;
@@ -758,15 +758,15 @@ __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
 }
 
 // Targets = real (code 0) entries whose original index lies in [tgt_begin, tgt_begin+n_tgt).
-__global__ void k_target_flags(int n_entries, const int* __restrict__ entries, int tgt_begin,
-                               int n_tgt, int* __restrict__ flag) {
+__global__ void k_target_flags(int n_entries, const int* __restrict__ entries,
+                               const uint8_t* __restrict__ codes, int tgt_begin, int n_tgt,
+                               int* __restrict__ flag) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n_entries) return;
     int f = 0;
     if (p < n_entries) {
-        const unsigned e = static_cast<unsigned>(entries[p]);
-        const int i = static_cast<int>(e & GHOST_INDEX_MASK);
-        f = ((e >> GHOST_SHIFT) == 0u && i >= tgt_begin && i < tgt_begin + n_tgt) ? 1 : 0;
+        const int i = entries[p];
+        f = (codes[p] == 0 && i >= tgt_begin && i - tgt_begin < n_tgt) ? 1 : 0;
     }
     flag[p] = f;  // entry n_entries is the trailing zero the scan needs
 }
@@ -808,7 +808,7 @@ struct P3MArgs {
     const double4* rec;      // sorted records incl. ghosts: {x, y, z, G*m}
     const float4* frec;      // the same positions rounded to fp32 (pre-filter)
     float prefilter_sq;      // fp32 r^2 bound that no pair with r^2 <= cutoff_sq can exceed
-    const int* entries;      // original index | image code << 26
+    const int* entries;      // original index of every sorted record
     const int* cell_start;   // [np^3 + 1]
     const int* tlist;        // sorted positions of the targets
     int n_entries;
@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
         az += __shfl_xor(az, d, 64);
     }
     if (live && sub == 0) {
-        const int o = static_cast<int>(static_cast<unsigned>(a.entries[p]) & GHOST_INDEX_MASK) - a.tgt_begin;
+        const int o = a.entries[p] - a.tgt_begin;
         a.ax[o] += ax; a.ay[o] += ay; a.az[o] += az;
     }
     if (a.accepted) {

@@ -496,6 +496,35 @@ def test_p3m_256cubed_sampled_targets_counts_and_momentum(lib, oracle):
         assert abs(s_) < 1e-9 * float((a.abs() * mm).sum().cpu())
 
 
+def test_p3m_beyond_2_to_26_sources(lib, oracle):
+    """407^3 = 67.4 M particles: more than 2^26, past what a packed index-plus-image-code entry
+    could address.  Sampled target slices against the oracle, counts exactly."""
+    import torch
+    n_side = 407
+    n = n_side ** 3
+    assert n > 1 << 26
+    pos = datasets.jittered_lattice(n_side)
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    m = np.full(n, config.DM_PARTICLE_MASS)
+    p = config.pp_params()
+    x, y, z, mm = _t(pos + [m])
+    rng = np.random.default_rng(12)
+    for begin in [0, n - 8] + [int(b) for b in rng.choice(n - 8, 2, replace=False)]:
+        part = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(3)]
+        lib.accumulate_device(p, x, y, z, mm, *part, tgt_begin=begin, n_tgt=8)
+        torch.cuda.synchronize()
+        assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
+        want = oracle.accumulate(p, *pos, m, tgt_begin=begin, n_tgt=8)
+        assert normalised_error([t.cpu().numpy() for t in part], want) < TOL
+        assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos, tgt_begin=begin, n_tgt=8)
+    acc = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    lib.accumulate_device(p, x, y, z, mm, *acc)
+    torch.cuda.synchronize()
+    assert 55 * n < lib.stats()["pairs_accepted"] < 75 * n
+    for a in acc:
+        assert abs(float((a * mm).sum().cpu())) < 1e-9 * float((a.abs() * mm).sum().cpu())
+
+
 # --------------------------------------------------------------------------------------
 # Zel'dovich initial conditions (the particle sets the reference actually starts from)
 # --------------------------------------------------------------------------------------
