@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--per-lane", type=int, default=0)
     ap.add_argument("--force-kernel", type=int, default=0)
     ap.add_argument("--p3m-radius", type=int, default=0)
+    ap.add_argument("--p3m-lanes", type=int, default=0, help="P3M cell kernel: lanes per target (0 = automatic)")
     ap.add_argument("--with-mesh", action="store_true",
                     help="p3m mode, one GPU: a step is the whole force phase, mesh force "
                          "(libnbpm) then short range accumulated onto it")
@@ -106,6 +107,7 @@ def main():
     lib.set_option(ffi.OPT_TARGETS_PER_LANE, args.per_lane)
     lib.set_option(ffi.OPT_FORCE_KERNEL, args.force_kernel)
     lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, args.p3m_radius)
+    lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, args.p3m_lanes)
     lib.set_option(ffi.OPT_DETERMINISTIC, 1 if args.ordered else 0)
 
     n_side = args.n_side
