@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-side", type=int, default=128)
+    ap.add_argument("--n-side", type=int, default=0,
+                    help="particles per side; default 128 (direct) or 256 (p3m), the headline sizes")
     ap.add_argument("--mode", choices=["direct", "p3m"], default="direct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-lane", type=int, default=0)
@@ -110,7 +111,7 @@ def main():
     lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, args.p3m_lanes)
     lib.set_option(ffi.OPT_DETERMINISTIC, 1 if args.ordered else 0)
 
-    n_side = args.n_side
+    n_side = args.n_side or (256 if args.mode == "p3m" else 128)
     n = n_side ** 3
     use_pm = args.mode == "p3m"
     config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm)
