@@ -420,8 +420,12 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     CHK(g.ghostcode.ensure(static_cast<size_t>(n_entries)));
     uint8_t* codes = g.ghostcode.as<uint8_t>();
     double4* rec = g.src.x.as<double4>();
-    CHK(g.src.y.ensure(sizeof(float4) * n_entries));   // and their fp32 copies in the y buffer
-    float4* frec = g.src.y.as<float4>();
+    // and their fp32 copies, one array per axis, in the y buffer
+    const size_t f_stride = (static_cast<size_t>(n_entries) + P3M_TRIP + 63) / 64 * 64;
+    CHK(g.src.y.ensure(sizeof(float) * 3 * f_stride));
+    float* fx = g.src.y.as<float>();
+    float* fy = fx + f_stride;
+    float* fz = fy + f_stride;
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
     hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
                        start, count, entries, codes);
@@ -430,7 +434,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     CHK(canonical_order(static_cast<int>(ncell), n_entries, start, entries, g.src.cell.as<int>(),
                         g.src.rank.as<int>(), s));
     hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
-                       cx, cy, cz, m, p->G, p->domain_size, rec, frec);
+                       cx, cy, cz, m, p->G, p->domain_size, rec, fx, fy, fz);
 
     // 3. compact list of targets in sorted order
     CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));
@@ -451,7 +455,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
 
     // 4. pairs
     P3MArgs a{};
-    a.rec = rec; a.frec = frec; a.prefilter_sq = p3m_prefilter_bound(p, grid);
+    a.rec = rec; a.fx = fx; a.fy = fy; a.fz = fz; a.prefilter_sq = p3m_prefilter_bound(p, grid);
     a.entries = entries; a.cell_start = start; a.tlist = tlist;
     a.n_entries = n_entries; a.n_tgt = n_tgt; a.tgt_begin = tgt_begin; a.g = grid;
     a.ax = ax; a.ay = ay; a.az = az;

@@ -745,7 +745,7 @@ __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
                                const uint8_t* __restrict__ codes, const double* __restrict__ x, const double* __restrict__ y,
                                const double* __restrict__ z, const double* __restrict__ m,
                                double G, double L, double4* __restrict__ rec,
-                               float4* __restrict__ frec) {
+                               float* __restrict__ fx, float* __restrict__ fy, float* __restrict__ fz) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_entries) return;
     const int i = entries[p];
@@ -753,8 +753,10 @@ __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
     const double4 r = make_double4(x[i] + image_shift(code & 3u, L), y[i] + image_shift((code >> 2) & 3u, L),
                                    z[i] + image_shift((code >> 4) & 3u, L), G * m[i]);
     rec[p] = r;
-    // single-precision copy for the cutoff pre-filter of k_p3m_cells
-    frec[p] = make_float4(static_cast<float>(r.x), static_cast<float>(r.y), static_cast<float>(r.z), 0.0f);
+    // single-precision copies for the cutoff pre-filter of k_p3m_cells, one array per axis
+    fx[p] = static_cast<float>(r.x);
+    fy[p] = static_cast<float>(r.y);
+    fz[p] = static_cast<float>(r.z);
 }
 
 // Targets = real (code 0) entries whose original index lies in [tgt_begin, tgt_begin+n_tgt).
@@ -806,7 +808,9 @@ __device__ __forceinline__ void p3m_accepted(double dx, double dy, double dz, do
 
 struct P3MArgs {
     const double4* rec;      // sorted records incl. ghosts: {x, y, z, G*m}
-    const float4* frec;      // the same positions rounded to fp32 (pre-filter)
+    const float* fx;         // the same positions rounded to fp32 (pre-filter), one array per
+    const float* fy;         // axis, each n_entries + P3M_TRIP long
+    const float* fz;
     float prefilter_sq;      // fp32 r^2 bound that no pair with r^2 <= cutoff_sq can exceed
     const int* entries;      // original index of every sorted record
     const int* cell_start;   // [np^3 + 1]
@@ -823,14 +827,16 @@ struct P3MArgs {
 constexpr int P3M_QCAP = 16;    // accepted-pair ring per lane (power of 2; 16 KiB LDS per workgroup)
 constexpr int P3M_DRAIN_UNROLL = 2;   // record fetches in flight per lane while draining
 constexpr int P3M_DRAIN = 8;   // entries every lane evaluates when some lane's ring is full
+constexpr int P3M_TRIP = 4;    // candidates a lane tests per trip of the filter loop (2 or 4)
 
 // One lane per target.  Two phases per lane, interleaved wave-wide:
-//   filter: walk the (2R+1)^2 runs, two candidates per trip, and push the sorted position of
-//           every candidate that may lie inside the cutoff onto the lane's ring in LDS (~30 %
-//           pass).  The test runs in single precision on 16-byte records against a bound that
-//           no pair inside the cutoff can exceed (P3MArgs::prefilter_sq): per candidate the
-//           vector cache returns 16 bytes per lane instead of 24, and the loop is bound by that
-//           return path as much as by instruction issue.
+//   filter: walk the (2R+1)^2 runs, P3M_TRIP candidates per trip, and push the sorted position
+//           of every candidate that may lie inside the cutoff onto the lane's ring in LDS (~30 %
+//           pass).  The test runs in single precision against a bound that no pair inside the
+//           cutoff can exceed (P3MArgs::prefilter_sq).  The fp32 coordinates sit in one array per
+//           axis, so a lane's P3M_TRIP consecutive candidates arrive as one vector per axis and
+//           the arithmetic is packed (v_pk_*_f32, two candidates per instruction) without any
+//           register shuffling; the loop is bound by instruction issue.
 //   drain:  when any lane's ring is full every lane evaluates its P3M_DRAIN oldest entries from
 //           the fp64 records: exact r^2, the reference's cutoff test (src/particles.cpp:326),
 //           then the full taper / double-softening arithmetic.  What a lane does not evaluate
@@ -845,28 +851,42 @@ __device__ __forceinline__ double4 load_record(const double4* rec, int idx) {
     return *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(rec) +
                                              (static_cast<uint32_t>(idx) << 5));
 }
-template <bool WIDE>
-__device__ __forceinline__ float4 load_frecord(const float4* rec, int idx) {
-    if constexpr (WIDE) return rec[idx];
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(rec) +
-                                            (static_cast<uint32_t>(idx) << 4));
-}
 __device__ __forceinline__ int load_word(const int* base, int idx) {   // idx < 2^30
     return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) +
                                          (static_cast<uint32_t>(idx) << 2));
 }
 static_assert((P3M_QCAP & (P3M_QCAP - 1)) == 0 && P3M_DRAIN % P3M_DRAIN_UNROLL == 0 &&
-              P3M_QCAP % P3M_DRAIN_UNROLL == 0, "ring sizes");
+              P3M_QCAP % P3M_DRAIN_UNROLL == 0 && P3M_DRAIN >= P3M_TRIP && (P3M_TRIP == 2 || P3M_TRIP == 4),
+              "ring sizes");
 __device__ __forceinline__ int ring_slot(int i) { return i & (P3M_QCAP - 1); }
 
-// 16-byte load that fetches nothing and returns zeros for lanes whose byte offset is past the
-// end of the buffer (hardware range check): masking a lane costs one select, no branch.
-__device__ __forceinline__ float4 load_frecord_checked(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 0);
-    const v4f f = __builtin_bit_cast(v4f, w);
-    return make_float4(f.x, f.y, f.z, f.w);
+// Loads that fetch nothing and return zeros for lanes whose byte offset is past the end of the
+// buffer (hardware range check): masking a lane costs one select, no branch.
+typedef float p3m_vf __attribute__((ext_vector_type(P3M_TRIP)));
+template <int T> struct p3m_fvec_load;
+template <> struct p3m_fvec_load<2> {
+    typedef float vf __attribute__((ext_vector_type(2)));
+    typedef unsigned vu __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ vf get(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
+        return __builtin_bit_cast(vf, (vu)__builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+    }
+};
+template <> struct p3m_fvec_load<4> {
+    typedef float vf __attribute__((ext_vector_type(4)));
+    typedef unsigned vu __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vf get(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
+        return __builtin_bit_cast(vf, (vu)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+};
+__device__ __forceinline__ p3m_vf load_fvec_checked(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
+    return p3m_fvec_load<P3M_TRIP>::get(rsrc, byte_offset);
+}
+// the same vector through a plain pointer (4-byte aligned)
+__device__ __forceinline__ p3m_vf load_fvec(const float* base, int idx) {
+    p3m_vf v;
+#pragma unroll
+    for (int u = 0; u < P3M_TRIP; ++u) v[u] = base[static_cast<size_t>(idx) + u];
+    return v;
 }
 
 __device__ __forceinline__ double4 load_record_checked(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
@@ -887,7 +907,7 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
     const bool live = t < a.n_tgt;
     const int p = a.tlist[live ? t : a.n_tgt - 1];
     const double4 me = a.rec[p];
-    const float4 mef = a.frec[p];
+    const p3m_vf nmx = -a.fx[p], nmy = -a.fy[p], nmz = -a.fz[p];   // splats
     const GhostGrid g = a.g;
     const PairConsts k = a.k;
     const float bound = a.prefilter_sq;
@@ -895,13 +915,16 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
     const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
     const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
     double ax = 0.0, ay = 0.0, az = 0.0;
-    int head = 0, cnt = 0;
+    int rp = 0, wp = 0;   // ring read / write positions, unwrapped: wp - rp entries are queued
+    int lim = P3M_QCAP - P3M_TRIP;   // the filter stops for a drain once some lane's wp exceeds it
     unsigned hits = 0;
-    // WIDE: more than 2^31 bytes of filter records; the range check then covers the first 2^31
-    // only and lanes are masked by pointing them at their own record instead
-    const uint32_t frec_bytes = WIDE ? 0x7ffffff0u : static_cast<uint32_t>(a.n_entries) << 4;
-    const __amdgpu_buffer_rsrc_t frec_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.frec), 0, frec_bytes, 0x00020000);
+    // the arrays are P3M_TRIP values longer than n_entries, so a vector that starts at a valid
+    // entry lies inside the range check.  WIDE: byte offsets may not fit 32 bits; plain pointer
+    // loads then, exhausted lanes pointed at their own record.
+    const uint32_t f_bytes = WIDE ? 0u : static_cast<uint32_t>(a.n_entries + P3M_TRIP) << 2;
+    const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fz), 0, f_bytes, 0x00020000);
 
     // evaluates up to `quota` (a multiple of DU) of the oldest queued candidates of every lane,
     // DU at a time so that DU record fetches are in flight together: the loop is a chain of
@@ -911,13 +934,14 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
     const __amdgpu_buffer_rsrc_t rec_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
     auto drain = [&](int quota) {
+        const int cnt = wp - rp;
 #pragma unroll 1
         for (int q = 0; q < quota && __any(q < cnt); q += DU) {
             double4 s[DU];
             bool valid[DU];
 #pragma unroll
             for (int u = 0; u < DU; ++u) {
-                const int idx = queue[q + u < cnt ? ring_slot(head + q + u) : 0][threadIdx.x];
+                const int idx = queue[q + u < cnt ? ring_slot(rp + q + u) : 0][threadIdx.x];
                 valid[u] = q + u < cnt && idx != p;   // the target itself passes the pre-filter
                 if constexpr (WIDE) s[u] = a.rec[valid[u] ? idx : p];
                 else s[u] = load_record_checked(rec_rsrc, valid[u] ? static_cast<uint32_t>(idx) << 5 : 0xffffffe0u);
@@ -932,9 +956,8 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
                 }
             }
         }
-        const int taken = min(quota, cnt);
-        head = ring_slot(head + taken);
-        cnt -= taken;
+        rp += min(quota, cnt);
+        lim = rp + (P3M_QCAP - P3M_TRIP);
     };
 
     // Rows (ox, oy) in [-R, R]^2, oy fastest; the wavefront walks them together (S = 1) or S at a
@@ -985,32 +1008,28 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
                     request_bounds(round);
                 }
             }
-            // two candidates per lane per trip; an exhausted lane fetches nothing and is rejected
-            const bool v0 = j < je, v1 = j + 1 < je;
-            float4 f0, f1;
+            // P3M_TRIP candidates per lane per trip; an exhausted lane fetches nothing
+            p3m_vf cx, cy, cz;
             if constexpr (WIDE) {
-                f0 = a.frec[v0 ? j : p];
-                f1 = a.frec[v1 ? j + 1 : p];
+                const int b = j < je ? j : p;
+                cx = load_fvec(a.fx, b); cy = load_fvec(a.fy, b); cz = load_fvec(a.fz, b);
             } else {
-                const uint32_t off = static_cast<uint32_t>(j) << 4;
-                f0 = load_frecord_checked(frec_rsrc, v0 ? off : 0xfffffff0u);
-                f1 = load_frecord_checked(frec_rsrc, v1 ? off + 16u : 0xfffffff0u);
+                const uint32_t off = j < je ? static_cast<uint32_t>(j) << 2 : 0xfffffff0u;
+                cx = load_fvec_checked(fx_rsrc, off);
+                cy = load_fvec_checked(fy_rsrc, off);
+                cz = load_fvec_checked(fz_rsrc, off);
             }
-            // the slot after the newest entry is free (cnt <= QCAP-2 here): the stores need no branch
-            {
-                const float dx = f0.x - mef.x, dy = f0.y - mef.y, dz = f0.z - mef.z;
-                const float r2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-                queue[ring_slot(head + cnt)][threadIdx.x] = j;
-                cnt += (v0 & !(r2 > bound)) ? 1 : 0;
+            const p3m_vf dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
+            const p3m_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+            // the slot after the newest entry is free (at most QCAP - P3M_TRIP queued on entry):
+            // the stores need no branch
+#pragma unroll
+            for (int u = 0; u < P3M_TRIP; ++u) {
+                queue[ring_slot(wp)][threadIdx.x] = j + u;
+                wp += ((j + u < je) & !(r2[u] > bound)) ? 1 : 0;
             }
-            {
-                const float dx = f1.x - mef.x, dy = f1.y - mef.y, dz = f1.z - mef.z;
-                const float r2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-                queue[ring_slot(head + cnt)][threadIdx.x] = j + 1;
-                cnt += (v1 & !(r2 > bound)) ? 1 : 0;
-            }
-            j += 2;
-            if (__any(cnt >= P3M_QCAP - 1)) break;
+            j += P3M_TRIP;
+            if (__any(wp > lim)) break;
         }
         drain(done ? P3M_QCAP : P3M_DRAIN);
     }

@@ -496,11 +496,13 @@ def test_p3m_256cubed_sampled_targets_counts_and_momentum(lib, oracle):
         assert abs(s_) < 1e-9 * float((a.abs() * mm).sum().cpu())
 
 
-def test_p3m_beyond_2_to_26_sources(lib, oracle):
+@pytest.mark.parametrize("n_side", [407, 512])
+def test_p3m_beyond_2_to_26_sources(lib, oracle, n_side):
     """407^3 = 67.4 M particles: more than 2^26, past what a packed index-plus-image-code entry
-    could address.  Sampled target slices against the oracle, counts exactly."""
+    could address.  512^3 = 2^27 particles: with their ghosts more than 2^27 records, which the
+    kernel addresses through 64-bit pointers instead of 32-bit byte offsets (its WIDE variant).
+    Sampled target slices against the oracle, counts exactly."""
     import torch
-    n_side = 407
     n = n_side ** 3
     assert n > 1 << 26
     pos = datasets.jittered_lattice(n_side)
