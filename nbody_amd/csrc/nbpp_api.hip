@@ -156,9 +156,9 @@ int exclusive_scan(int n, const int* count, int* start, hipStream_t s) {
     const int nblocks = cdiv(n, SCAN_BLOCK);
     CHK(g.blocksum.ensure(sizeof(int) * (nblocks + 1)));
     int* bs = g.blocksum.as<int>();
-    hipLaunchKernelGGL(k_scan_blocks, dim3(nblocks), dim3(WG), 0, s, n, count, start, bs);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(WG), 0, s, n, count, bs);
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(WG), 0, s, nblocks, bs, bs + nblocks);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(WG), 0, s, n, start, bs);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(WG), 0, s, n, count, start, bs);
     HIPCHK(hipGetLastError());
     return NBPP_OK;
 }
@@ -403,10 +403,9 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     CHK(g.src.start.ensure(sizeof(int) * (ncell + 1)));
     int* count = g.count.as<int>();
     int* start = g.src.start.as<int>();
-    hipLaunchKernelGGL(k_canonical_positions, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z,
-                       p->domain_size, cx, cy, cz);
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
-    hipLaunchKernelGGL(k_ghost_count, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid, count);
+    hipLaunchKernelGGL(k_ghost_count, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z, grid, cx, cy, cz,
+                       count);
     CHK(exclusive_scan(static_cast<int>(ncell + 1), count, start, s));
     int n_entries = 0;  // the one host read-back of the call: real + ghost entries
     HIPCHK(hipMemcpyAsync(&n_entries, start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -426,7 +425,6 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     float* fx = g.src.y.as<float>();
     float* fy = fx + f_stride;
     float* fz = fy + f_stride;
-    HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
     hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
                        start, count, entries, codes);
     CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));   // scratch here, target flags / slots below
@@ -436,18 +434,32 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
                        cx, cy, cz, m, p->G, p->domain_size, rec, fx, fy, fz);
 
-    // 3. compact list of targets in sorted order
-    CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));
-    CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
+    // 3. list of targets in sorted order
     CHK(g.tgt.order.ensure(sizeof(int) * n_tgt));
-    int* flag = g.src.cell.as<int>();
-    int* slot = g.src.rank.as<int>();
     int* tlist = g.tgt.order.as<int>();
-    hipLaunchKernelGGL(k_target_flags, dim3(cdiv(n_entries + 1, WG)), dim3(WG), 0, s, n_entries, entries, codes,
-                       tgt_begin, n_tgt, flag);
-    CHK(exclusive_scan(n_entries + 1, flag, slot, s));
-    hipLaunchKernelGGL(k_target_scatter, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, flag, slot,
-                       tlist);
+    if (tgt_begin == 0 && n_tgt == n_src) {
+        // every real entry: one contiguous piece per column of the grid
+        const int ncol = grid.np * grid.np;
+        CHK(g.src.cell.ensure(sizeof(int) * (ncol + 1)));
+        CHK(g.src.rank.ensure(sizeof(int) * (ncol + 1)));
+        int* col_count = g.src.cell.as<int>();
+        int* col_start = g.src.rank.as<int>();
+        hipLaunchKernelGGL(k_column_counts, dim3(cdiv(ncol + 1, WG)), dim3(WG), 0, s, grid, start, col_count);
+        CHK(exclusive_scan(ncol + 1, col_count, col_start, s));
+        hipLaunchKernelGGL(k_column_targets, dim3(std::min(ncol, 65536)), dim3(WG), 0, s, grid, start, col_start,
+                           tlist);
+    } else {
+        // a slice of the particles: flag the real entries in it and compact
+        CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));
+        CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
+        int* flag = g.src.cell.as<int>();
+        int* slot = g.src.rank.as<int>();
+        hipLaunchKernelGGL(k_target_flags, dim3(cdiv(n_entries + 1, WG)), dim3(WG), 0, s, n_entries, entries, codes,
+                           tgt_begin, n_tgt, flag);
+        CHK(exclusive_scan(n_entries + 1, flag, slot, s));
+        hipLaunchKernelGGL(k_target_scatter, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, flag, slot,
+                           tlist);
+    }
     HIPCHK(hipGetLastError());
     CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));

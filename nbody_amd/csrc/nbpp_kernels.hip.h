@@ -166,9 +166,13 @@ __global__ void k_bin_count(int n, const double* __restrict__ x, const double* _
     rank[i] = atomicAdd(&count[c], 1);
 }
 
-// Exclusive scan in three launches: 2048 entries per block.
-constexpr int SCAN_PER_THREAD = 8;
-constexpr int SCAN_BLOCK = WG * SCAN_PER_THREAD;
+// Exclusive scan in three launches (block sums, scan of the sums, scan with the block's offset):
+// the input is read twice and the output written once, all in 16-byte accesses in which
+// neighbouring lanes touch neighbouring addresses.  A block covers SCAN_SUBS sub-blocks of 1024
+// entries; both arrays must be 16-byte aligned.
+constexpr int SCAN_SUB = WG * 4;
+constexpr int SCAN_SUBS = 4;
+constexpr int SCAN_BLOCK = SCAN_SUB * SCAN_SUBS;
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total) {
     // inclusive scan over 256 threads via wave shuffles + 4 wave totals in LDS
@@ -188,25 +192,25 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total)
     return base + inc - v;
 }
 
-__global__ void __launch_bounds__(WG) k_scan_blocks(int n, const int* __restrict__ in,
-                                                    int* __restrict__ out,
+__device__ __forceinline__ int4 scan_load(const int* __restrict__ in, int i, int n) {   // zeros past n
+    if (i + 3 < n) return *reinterpret_cast<const int4*>(in + i);
+    return make_int4(i < n ? in[i] : 0, i + 1 < n ? in[i + 1] : 0, i + 2 < n ? in[i + 2] : 0, 0);
+}
+
+__global__ void __launch_bounds__(WG) k_scan_reduce(int n, const int* __restrict__ in,
                                                     int* __restrict__ block_sum) {
-    __shared__ int lds[4];
-    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    int v[SCAN_PER_THREAD], s = 0;
+    __shared__ int lds[WG / 64];
+    int s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
-        s += v[k];
+    for (int k = 0; k < SCAN_SUBS; ++k) {
+        const int4 v = scan_load(in, blockIdx.x * SCAN_BLOCK + k * SCAN_SUB + threadIdx.x * 4, n);
+        s += (v.x + v.y) + (v.z + v.w);
     }
-    int total;
-    int run = block_exclusive_scan(s, lds, total);
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        if (base + k < n) out[base + k] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
 // One workgroup scans the per-block totals in place (exclusive) and stores the grand total
@@ -226,13 +230,28 @@ __global__ void __launch_bounds__(WG) k_scan_totals(int nblocks, int* __restrict
     if (threadIdx.x == 0) out_total[0] = carry;
 }
 
-__global__ void __launch_bounds__(WG) k_scan_add(int n, int* __restrict__ out,
-                                                 const int* __restrict__ block_sum) {
-    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    const int add = block_sum[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k)
-        if (base + k < n) out[base + k] += add;
+// out[i] = block offset + sum of the block's entries before i
+__global__ void __launch_bounds__(WG) k_scan_apply(int n, const int* __restrict__ in,
+                                                   int* __restrict__ out,
+                                                   const int* __restrict__ block_sum) {
+    __shared__ int lds[WG / 64];
+    int carry = block_sum[blockIdx.x];
+#pragma unroll 1
+    for (int k = 0; k < SCAN_SUBS; ++k) {
+        const int i = blockIdx.x * SCAN_BLOCK + k * SCAN_SUB + threadIdx.x * 4;
+        const int4 v = scan_load(in, i, n);
+        int total;
+        const int run = carry + block_exclusive_scan((v.x + v.y) + (v.z + v.w), lds, total);
+        const int4 o = make_int4(run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z);
+        if (i + 3 < n) {
+            *reinterpret_cast<int4*>(out + i) = o;
+        } else {
+            if (i < n) out[i] = o.x;
+            if (i + 1 < n) out[i + 1] = o.y;
+            if (i + 2 < n) out[i + 2] = o.z;
+        }
+        carry += total;
+    }
 }
 
 __global__ void k_bin_scatter(int n, const int* __restrict__ cell, const int* __restrict__ rank,
@@ -336,17 +355,6 @@ __device__ __forceinline__ double canonical(double x, double L) {
     x = (x >= L) ? x - L : x;
     x = (x < 0.0) ? x + L : x;
     return (x >= L) ? 0.0 : x;
-}
-
-__global__ void k_canonical_positions(int n, const double* __restrict__ x,
-                                      const double* __restrict__ y, const double* __restrict__ z,
-                                      double L, double* __restrict__ cx, double* __restrict__ cy,
-                                      double* __restrict__ cz) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    cx[i] = canonical(x[i], L);
-    cy[i] = canonical(y[i], L);
-    cz[i] = canonical(z[i], L);
 }
 
 __global__ void k_gather_targets(int n, int npad, const int* __restrict__ order,
@@ -715,15 +723,21 @@ __device__ __forceinline__ void for_each_image(double x, double y, double z, con
                   static_cast<unsigned>(code[0][ix] | (code[1][iy] << 2) | (code[2][iz] << 4)));
 }
 
+// Brings the positions into [0, L) (kept in cx, cy, cz for the passes after this one) and counts
+// every image's cell.
 __global__ void k_ghost_count(int n, const double* __restrict__ x, const double* __restrict__ y,
-                              const double* __restrict__ z, GhostGrid g, int* __restrict__ count) {
+                              const double* __restrict__ z, GhostGrid g, double* __restrict__ cx,
+                              double* __restrict__ cy, double* __restrict__ cz, int* __restrict__ count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned) { atomicAdd(&count[cell], 1); });
+    const double px = canonical(x[i], g.L), py = canonical(y[i], g.L), pz = canonical(z[i], g.L);
+    cx[i] = px; cy[i] = py; cz[i] = pz;
+    for_each_image(px, py, pz, g, [&](int cell, unsigned) { atomicAdd(&count[cell], 1); });
 }
 
-// `fill` starts at zero; the within-cell order produced here is arbitrary and is made
-// deterministic by k_cell_canon / k_cell_canon_big afterwards.
+// `fill` holds the cell counts of k_ghost_count and is counted down to zero, a cell's slots being
+// handed out from its last to its first; the within-cell order produced here is arbitrary and is
+// made deterministic by k_cell_canon / k_cell_canon_big afterwards.
 __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const double* __restrict__ y,
                                 const double* __restrict__ z, GhostGrid g,
                                 const int* __restrict__ start, int* __restrict__ fill,
@@ -731,7 +745,7 @@ __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const doubl
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned code) {
-        const int slot = start[cell] + atomicAdd(&fill[cell], 1);
+        const int slot = start[cell] + atomicSub(&fill[cell], 1) - 1;
         entries[slot] = i;
         codes[slot] = static_cast<uint8_t>(code);
     });
@@ -777,6 +791,35 @@ __global__ void k_target_scatter(int n_entries, const int* __restrict__ flag,
                                  const int* __restrict__ slot, int* __restrict__ tlist) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n_entries && flag[p]) tlist[slot[p]] = p;
+}
+
+// When every particle is a target the list is the real entries in sorted order, and those are
+// one contiguous piece per z column of the padded grid (cells R .. np-R-1 of a column that is
+// not itself a ghost column).  count[col] = real entries of column col; count[np^2] = 0.
+__global__ void k_column_counts(GhostGrid g, const int* __restrict__ cell_start, int* __restrict__ count) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = g.np * g.np;
+    if (col > ncol) return;
+    int c = 0;
+    if (col < ncol) {
+        const int X = col / g.np, Y = col - X * g.np;
+        if (X >= g.R && X < g.np - g.R && Y >= g.R && Y < g.np - g.R)
+            c = cell_start[col * g.np + g.np - g.R] - cell_start[col * g.np + g.R];
+    }
+    count[col] = c;
+}
+
+// col_start = exclusive scan of the counts above: the list positions of a column's real entries
+__global__ void __launch_bounds__(WG) k_column_targets(GhostGrid g, const int* __restrict__ cell_start,
+                                                       const int* __restrict__ col_start,
+                                                       int* __restrict__ tlist) {
+    const int ncol = g.np * g.np;
+    for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
+        const int at = col_start[col], cnt = col_start[col + 1] - at;
+        if (cnt == 0) continue;
+        const int first = cell_start[col * g.np + g.R];
+        for (int k = threadIdx.x; k < cnt; k += WG) tlist[at + k] = first + k;
+    }
 }
 
 // The accepted-pair arithmetic of src/particles.cpp:330-359 for one (target, source) pair with
