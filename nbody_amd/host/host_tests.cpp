@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -26,6 +28,7 @@
 #include "ics.hpp"
 #include "integrator.hpp"
 #include "particles.hpp"
+#include "snapshot.hpp"
 
 using namespace nbh;
 
@@ -247,6 +250,34 @@ int main(int argc, char** argv) {
             std::fclose(f);
             return 0;
         }
+        if (argc >= 4 && !std::strcmp(argv[1], "snapshot")) {
+            // a patterned state of the size <ini> asks for as snapshot_0007.hdf5 in <dir>: no GPU
+            // involved.  Particle i sits at ((i + 0.25) / n, (i + 0.5) / n, (i + 0.75) / n) L with
+            // velocity (i, -i, 2 i) and acceleration (0.5 i, 0, -0.5 i); gas mesh k holds
+            // k + 1 + cell index / 1024.
+            Config config;
+            config.load(argv[2]);
+            ParticleSystem dm(config);
+            const int n = config.NUM_DM_PARTICLES;
+            for (int i = 0; i < n; ++i) {
+                dm.add_particle((i + 0.25) / n * config.DOMAIN_SIZE, (i + 0.5) / n * config.DOMAIN_SIZE,
+                                (i + 0.75) / n * config.DOMAIN_SIZE, i, -i, 2.0 * i, config.DM_PARTICLE_MASS);
+                dm.acc_x[i] = 0.5 * i;
+                dm.acc_z[i] = -0.5 * i;
+            }
+            std::vector<double> gas[9];
+            if (config.USE_HYDRO) {
+                const std::size_t cells = static_cast<std::size_t>(config.MESH_SIZE) * config.MESH_SIZE * config.MESH_SIZE;
+                for (int k = 0; k < 9; ++k) {
+                    gas[k].resize(cells);
+                    for (std::size_t c = 0; c < cells; ++c) gas[k][c] = k + 1 + static_cast<double>(c) / 1024.0;
+                }
+            }
+            SnapshotWriter writer(argv[3], config);
+            writer.save_snapshot(7, 0, dm, gas, 1.25, config.START_A, config);
+            std::printf("wrote %s\n", writer.path_of(7).c_str());
+            return 0;
+        }
         if (argc >= 4 && !std::strcmp(argv[1], "run")) {
             if (nbpp_init(0) != NBPP_OK) { std::printf("nbpp_init failed: %s\n", nbpp_last_error()); return 2; }
             nbpp_set_option(NBPP_OPT_TIMING, 1);
@@ -276,10 +307,15 @@ int main(int argc, char** argv) {
             };
             report("initial");
             // Snapshots with the reference's cadence (src/engine.cpp:28-33, :56-67): one at the start,
-            // one whenever a passes next_output_a, one at the end.  Raw little-endian doubles, not
-            // HDF5: {n, mesh, a, t, L, use_hydro}, x, y, z, mass[n], then gas density and energy
-            // [mesh^3] with hydro.
+            // one whenever a passes next_output_a, one at the end.  If the fourth argument names a
+            // directory: snapshot_%04d.hdf5 files in it, the reference's layout (snapshot.hpp).
+            // Otherwise it is a file prefix for raw little-endian doubles:
+            // {n, mesh, a, t, L, use_hydro}, x, y, z, mass[n], then gas density and energy [mesh^3]
+            // with hydro.
             const char* snap_prefix = argc >= 5 ? argv[4] : nullptr;
+            std::unique_ptr<SnapshotWriter> hdf5;
+            if (snap_prefix && std::filesystem::is_directory(snap_prefix))
+                hdf5.reset(new SnapshotWriter(snap_prefix, config));
             int snapshot_count = 0;
             double next_output_a = config.START_A + config.SAVE_HDF5_EVERY_DELTA_A;
             auto save_snapshot = [&]() {
@@ -288,6 +324,11 @@ int main(int argc, char** argv) {
                 engine.download(now);
                 std::vector<double> gas[9];
                 engine.download_gas(gas);
+                if (hdf5) {
+                    hdf5->save_snapshot(snapshot_count++, engine.cycle_count, now, gas, engine.cosmo.total_time,
+                                        engine.cosmo.scale_factor, config);
+                    return;
+                }
                 char name[1024];
                 std::snprintf(name, sizeof(name), "%s_%04d.bin", snap_prefix, snapshot_count++);
                 FILE* f = std::fopen(name, "wb");
@@ -394,7 +435,7 @@ int main(int argc, char** argv) {
             nbpp_shutdown();
             return rc;
         }
-        std::printf("usage: %s config [ini] | gpu-tests | kdk <in> <out> <steps> <dt> <ini> | run <ini> <cycles> [snapshot-prefix [log-dir]]\n", argv[0]);
+        std::printf("usage: %s config [ini] | snapshot <ini> <dir> | gpu-tests | kdk <in> <out> <steps> <dt> <ini> | run <ini> <cycles> [snapshot-prefix|snapshot-dir [log-dir]]\n", argv[0]);
         return 64;
     } catch (const std::exception& e) {
         std::printf("error: %s\n", e.what());
