@@ -3,7 +3,7 @@
 the 8-GPU configuration): full evaluation on one GPU, a sample of targets against the CPU oracle,
 and total-momentum conservation.  Too long for the regular test suite (~100 s of GPU at 256^3).
 
-usage: python tools/validate_large.py [n_side] [n_sample]
+usage: python tests/large_validation.py [n_side] [n_sample]
 """
 import os
 import sys
@@ -13,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
