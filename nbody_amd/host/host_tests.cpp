@@ -12,6 +12,7 @@
 //   nbody_host_tests engine <in.bin> <out.bin> <steps> <dt> <ini>
 //                                          the same steps with the state resident on the GPU
 #include <chrono>
+#include <csignal>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -226,6 +227,11 @@ static int run_kdk(const char* in_path, const char* out_path, int steps, double 
     return 0;
 }
 
+// Ctrl+C finishes the cycle in flight, writes the last snapshot and diagnostics line and ends the
+// run with exit=2 (UserAborted), as src/main.cpp:13-22 and src/engine.cpp:79 do.
+volatile std::sig_atomic_t g_stop_requested = 0;
+extern "C" void on_sigint(int) { g_stop_requested = 1; }
+
 int main(int argc, char** argv) {
     try {
         if (argc >= 2 && !std::strcmp(argv[1], "config")) {
@@ -379,7 +385,8 @@ int main(int argc, char** argv) {
             const auto t0 = std::chrono::steady_clock::now();
             // engine.run() (src/engine.cpp:78-91) unrolled, to log like the reference does every
             // DEBUG_INFO_EVERY_CYCLES cycles (src/engine.cpp:69-75)
-            while (engine.needs_more_cycles) {
+            std::signal(SIGINT, on_sigint);
+            while (engine.needs_more_cycles && !g_stop_requested) {
                 engine.step();
                 if (config.DEBUG_INFO_EVERY_CYCLES > 0 && engine.cycle_count % config.DEBUG_INFO_EVERY_CYCLES == 0) {
                     nbpp_stats ps{};
@@ -390,17 +397,19 @@ int main(int argc, char** argv) {
                                 ps.total_ms > 0 ? ps.pairs_accepted / ps.total_ms * 1e-6 : 0.0);
                     std::fflush(stdout);
                 }
+                const bool last_cycle = !engine.needs_more_cycles || g_stop_requested;
                 if (config.DEBUG_INFO_EVERY_CYCLES > 0 &&
-                    (!engine.needs_more_cycles || engine.cycle_count % config.DEBUG_INFO_EVERY_CYCLES == 0))
+                    (last_cycle || engine.cycle_count % config.DEBUG_INFO_EVERY_CYCLES == 0))
                     log_diagnostics();
                 const bool must_save = engine.cosmo.scale_factor >= next_output_a;
-                if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0 && (!engine.needs_more_cycles || must_save)) {
+                if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0 && (last_cycle || must_save)) {
                     save_snapshot();
                     while (next_output_a <= engine.cosmo.scale_factor) next_output_a += config.SAVE_HDF5_EVERY_DELTA_A;
                 }
             }
-            const ExitStatus st = engine.cycle_count >= config.MAX_CYCLES ? ExitStatus::ReachedMaxCycles
-                                                                          : ExitStatus::ReachedMaxScaleFactor;
+            const ExitStatus st = g_stop_requested ? ExitStatus::UserAborted
+                                  : engine.cycle_count >= config.MAX_CYCLES ? ExitStatus::ReachedMaxCycles
+                                                                            : ExitStatus::ReachedMaxScaleFactor;
             const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             report("final");
             std::printf("timing: %ld cycles, %.3f ms/cycle wall; PP %.3f, mesh %.3f, hydro sweeps %.3f ms/cycle (device); exit=%d\n",
