@@ -90,7 +90,7 @@ void DeviceEngine::compute_accelerations() {
     if (config_.USE_PM || config_.USE_HYDRO) {                               // :239-245
         // bin_and_assign_mass, total density, Poisson solve; the gas kick reads the meshes too
         const nbpm_params mp = config_.mesh_params();
-        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), nullptr), "event");
+        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), nullptr), "event");
         nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], nullptr));
         const double* source = mesh_[0];
         if (config_.USE_HYDRO) {                                             // :57-59
@@ -103,11 +103,13 @@ void DeviceEngine::compute_accelerations() {
         if (config_.USE_PM)
             nbpm_check(nbpm_interpolate_device(&mp, n_, dev_[0], dev_[1], dev_[2], mesh_[2], mesh_[3], mesh_[4],
                                                dev_[6], dev_[7], dev_[8], nullptr));
-        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), nullptr), "event");
-        hip_check(hipEventSynchronize(static_cast<hipEvent_t>(ev_[1])), "event");
-        float ms = 0.0f;
-        hip_check(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(ev_[0]), static_cast<hipEvent_t>(ev_[1])), "event");
-        pm_ms += ms;
+        if (timed_) {
+            hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), nullptr), "event");
+            hip_check(hipEventSynchronize(static_cast<hipEvent_t>(ev_[1])), "event");
+            float ms = 0.0f;
+            hip_check(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(ev_[0]), static_cast<hipEvent_t>(ev_[1])), "event");
+            pm_ms += ms;
+        }
     }
     if (!config_.USE_PM) {                                                   // :246-251
         for (int c = 6; c < 9; ++c)
@@ -116,11 +118,13 @@ void DeviceEngine::compute_accelerations() {
     }
     if (config_.USE_PP && n_) {                                              // :254-258
         const nbpp_params p = config_.pp_params();
+        nbpp_check(nbpp_set_option(NBPP_OPT_TIMING, timed_ ? 1 : 0));
         nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_,
                                           dev_[6], dev_[7], dev_[8], nullptr));
         nbpp_stats st;
-        if (nbpp_get_stats(&st) == NBPP_OK) pp_ms += st.total_ms;
+        if (timed_ && nbpp_get_stats(&st) == NBPP_OK) pp_ms += st.total_ms;
     }
+    if (timed_) ++timed_force_calls;
     if (!config_.STANDING_PARTICLES) {                                       // :261-262
         nbpp_check(nbpp_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, nullptr));
     } else {                                                                 // :263-269
@@ -168,6 +172,7 @@ void DeviceEngine::download_mesh_solve(std::vector<double>& total_rho, std::vect
 }
 
 void DeviceEngine::step() {
+    timed_ = timing_every > 0 && (cycle_count + 1) % timing_every == 0;
     const double dt = current_dt;
     const nbgas_params gp = config_.gas_params();
     const nbgas_state gs = gas_state();
@@ -180,9 +185,9 @@ void DeviceEngine::step() {
     nbpp_check(nbpp_drift_device(n_, dev_[0], dev_[1], dev_[2], dev_[3], dev_[4], dev_[5], dt,
                                  config_.DOMAIN_SIZE, nullptr));                        // :224
     if (config_.USE_HYDRO) {                                                            // :227-230
-        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), nullptr), "event");
+        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), nullptr), "event");
         nbgas_check(nbgas_hydro_step_device(&gp, &gs, dt, nullptr));
-        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), nullptr), "event");
+        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), nullptr), "event");
     }
     cosmo.total_time += dt;                                                             // :233
     update_cosmology(cosmo, config_);                                                   // :234
@@ -193,7 +198,8 @@ void DeviceEngine::step() {
     nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
                                 cosmo.scale_factor, cosmo.hubble_param, nullptr));      // :274
     ++cycle_count;
-    if (config_.USE_HYDRO) {
+    if (timed_) ++timed_steps;
+    if (config_.USE_HYDRO && timed_) {
         hip_check(hipEventSynchronize(static_cast<hipEvent_t>(ev_[3])), "event");
         float ms = 0.0f;
         hip_check(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(ev_[2]), static_cast<hipEvent_t>(ev_[3])), "event");

@@ -46,9 +46,15 @@ class DeviceEngine {
     bool needs_more_cycles = true;
     Cosmology cosmo;
     double max_accel_sq = 1e-9;
-    double pp_ms = 0.0;                  // accumulated device time of the PP force calls
-    double pm_ms = 0.0;                  // accumulated device time of the mesh force calls
-    double gas_ms = 0.0;                 // accumulated device time of the gas solver and its kicks
+    // Device times are measured with events, and reading an event means waiting for the GPU: on
+    // small problems that wait costs more than the kernels it times.  Cycles whose number is a
+    // multiple of timing_every are timed (1: every cycle, 0: none); the sums below cover those only.
+    int timing_every = 1;
+    long timed_force_calls = 0;          // force phases (the initial one included) the sums cover
+    long timed_steps = 0;                // cycles gas_ms covers
+    double pp_ms = 0.0;                  // device time of the timed PP force calls
+    double pm_ms = 0.0;                  // device time of the timed mesh force calls
+    double gas_ms = 0.0;                 // device time of the timed gas sweeps
 
    private:
     void compute_accelerations();        // src/integrator.cpp:236-269
@@ -60,6 +66,7 @@ class DeviceEngine {
     double* gas_[9] = {};                // GasGrid's meshes, in nbgas_state order
     double* mesh_[5] = {};               // dm density, total density, gravity x y z
     bool stop_requested_ = false;
+    bool timed_ = true;                  // the force phase / cycle in flight is being timed
     void* ev_[4] = {};                   // hipEvent_t: mesh begin/end, gas begin/end
 };
 

@@ -294,6 +294,9 @@ int main(int argc, char** argv) {
             ZeldovichField field;
             ParticleSystem dm = initialize_particles(config, cosmo, &field);
             DeviceEngine engine(config, dm, config.USE_HYDRO ? &field : nullptr);
+            // device times are sampled on the cycles that print them (optional fifth argument:
+            // another sampling interval, 1 = every cycle)
+            engine.timing_every = argc >= 7 ? std::atoi(argv[6]) : std::max(1, config.DEBUG_INFO_EVERY_CYCLES);
             auto report = [&](const char* when) {
                 ParticleSystem now(config);
                 engine.download(now);
@@ -312,6 +315,9 @@ int main(int argc, char** argv) {
                 }
             };
             report("initial");
+            // the first force phase also pays for set-up (FFT plans, buffers): keep it out of the averages
+            engine.pp_ms = engine.pm_ms = engine.gas_ms = 0.0;
+            engine.timed_force_calls = engine.timed_steps = 0;
             // Snapshots with the reference's cadence (src/engine.cpp:28-33, :56-67): one at the start,
             // one whenever a passes next_output_a, one at the end.  If the fourth argument names a
             // directory: snapshot_%04d.hdf5 files in it, the reference's layout (snapshot.hpp).
@@ -355,8 +361,8 @@ int main(int argc, char** argv) {
             // diagnostics.csv in the directory given as the fifth argument, with the reference's
             // columns and cadence (src/engine.cpp:24-26, :69-75)
             Logger logger(argc >= 6 ? argv[5] : "/nonexistent");
-            long logged_cycle = 0;
-            double logged_ms[3] = {0.0, 0.0, 0.0};
+            long logged_cycle = 0, logged_calls = 0, logged_steps = 0;
+            double logged_ms[3] = {0.0, 0.0, 0.0}, last_avg[3] = {0.0, 0.0, 0.0};
             auto logged_wall = std::chrono::steady_clock::now();
             auto log_diagnostics = [&]() {
                 if (!logger.is_open()) return;
@@ -372,13 +378,23 @@ int main(int argc, char** argv) {
                 const auto wall_now = std::chrono::steady_clock::now();
                 if (cycles > 0) {                                    // averages since the last line
                     d.avg_step = std::chrono::duration<double>(wall_now - logged_wall).count() / cycles;
-                    d.avg_pm = (engine.pm_ms - logged_ms[0]) * 1e-3 / cycles;
-                    d.avg_pp = (engine.pp_ms - logged_ms[1]) * 1e-3 / cycles;
-                    d.avg_hydro = (engine.gas_ms - logged_ms[2]) * 1e-3 / cycles;
+                    // device times: averages over the cycles since the last line that were timed
+                    // (none timed, as can happen for the last line of a run: the averages before it)
+                    const long calls = engine.timed_force_calls - logged_calls;
+                    const long steps = engine.timed_steps - logged_steps;
+                    if (calls > 0) {
+                        last_avg[0] = (engine.pm_ms - logged_ms[0]) * 1e-3 / calls;
+                        last_avg[1] = (engine.pp_ms - logged_ms[1]) * 1e-3 / calls;
+                    }
+                    if (steps > 0) last_avg[2] = (engine.gas_ms - logged_ms[2]) * 1e-3 / steps;
+                    d.avg_pm = last_avg[0];
+                    d.avg_pp = last_avg[1];
+                    d.avg_hydro = last_avg[2];
                 }
                 logger.log(d);
                 logged_cycle = engine.cycle_count;
                 logged_ms[0] = engine.pm_ms; logged_ms[1] = engine.pp_ms; logged_ms[2] = engine.gas_ms;
+                logged_calls = engine.timed_force_calls; logged_steps = engine.timed_steps;
                 logged_wall = std::chrono::steady_clock::now();
             };
             log_diagnostics();
@@ -412,10 +428,10 @@ int main(int argc, char** argv) {
                                                                             : ExitStatus::ReachedMaxScaleFactor;
             const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             report("final");
-            std::printf("timing: %ld cycles, %.3f ms/cycle wall; PP %.3f, mesh %.3f, hydro sweeps %.3f ms/cycle (device); exit=%d\n",
+            std::printf("timing: %ld cycles, %.3f ms/cycle wall; PP %.3f, mesh %.3f, hydro sweeps %.3f ms/cycle (device, %ld timed cycles); exit=%d\n",
                         engine.cycle_count, wall_ms / std::max(1L, engine.cycle_count),
-                        engine.pp_ms / (engine.cycle_count + 1), engine.pm_ms / (engine.cycle_count + 1),
-                        engine.gas_ms / std::max(1L, engine.cycle_count), static_cast<int>(st));
+                        engine.pp_ms / std::max(1L, engine.timed_force_calls), engine.pm_ms / std::max(1L, engine.timed_force_calls),
+                        engine.gas_ms / std::max(1L, engine.timed_steps), engine.timed_steps, static_cast<int>(st));
             nbgas_shutdown();
             nbpm_shutdown();
             nbpp_shutdown();
@@ -444,7 +460,7 @@ int main(int argc, char** argv) {
             nbpp_shutdown();
             return rc;
         }
-        std::printf("usage: %s config [ini] | snapshot <ini> <dir> | gpu-tests | kdk <in> <out> <steps> <dt> <ini> | run <ini> <cycles> [snapshot-prefix|snapshot-dir [log-dir]]\n", argv[0]);
+        std::printf("usage: %s config [ini] | snapshot <ini> <dir> | gpu-tests | kdk <in> <out> <steps> <dt> <ini> | run <ini> <cycles> [snapshot-prefix|snapshot-dir [log-dir [timing-every]]]\n", argv[0]);
         return 64;
     } catch (const std::exception& e) {
         std::printf("error: %s\n", e.what());
