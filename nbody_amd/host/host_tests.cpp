@@ -294,9 +294,11 @@ int main(int argc, char** argv) {
             ZeldovichField field;
             ParticleSystem dm = initialize_particles(config, cosmo, &field);
             DeviceEngine engine(config, dm, config.USE_HYDRO ? &field : nullptr);
-            // device times are sampled on the cycles that print them (optional fifth argument:
-            // another sampling interval, 1 = every cycle)
-            engine.timing_every = argc >= 7 ? std::atoi(argv[6]) : std::max(1, config.DEBUG_INFO_EVERY_CYCLES);
+            // device times are sampled on the cycles that print them, and on the last one of a run
+            // bounded by its cycle count (optional sixth argument: another sampling interval, 1 =
+            // every cycle)
+            engine.timing_every = argc >= 7 ? std::atoi(argv[6])
+                                            : std::max(1, std::min(config.DEBUG_INFO_EVERY_CYCLES, config.MAX_CYCLES));
             auto report = [&](const char* when) {
                 ParticleSystem now(config);
                 engine.download(now);
