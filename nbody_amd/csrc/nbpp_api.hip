@@ -477,7 +477,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // lanes per target: enough lanes for every SIMD to hold several wavefronts
     int lanes = 1;
     while (lanes < 8 && static_cast<long long>(n_tgt) * lanes < 400000) lanes *= 2;
-    if (g.opt_p3m_lanes == 1 || g.opt_p3m_lanes == 2 || g.opt_p3m_lanes == 4 || g.opt_p3m_lanes == 8)
+    if (g.opt_p3m_lanes == 1 || g.opt_p3m_lanes == 2 || g.opt_p3m_lanes == 4 || g.opt_p3m_lanes == 8 ||
+        g.opt_p3m_lanes == 16)
         lanes = static_cast<int>(g.opt_p3m_lanes);
     const dim3 grid_dim(cdiv(static_cast<long long>(n_tgt) * lanes, WG)), wg_dim(WG);
     const bool soft0 = p->soft_sq == 0.0;
@@ -487,7 +488,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         case 1: NBPP_LAUNCH_P3M(S0, W, 1); break;                   \
         case 2: NBPP_LAUNCH_P3M(S0, W, 2); break;                   \
         case 4: NBPP_LAUNCH_P3M(S0, W, 4); break;                   \
-        default: NBPP_LAUNCH_P3M(S0, W, 8); break;                  \
+        case 8: NBPP_LAUNCH_P3M(S0, W, 8); break;                   \
+        default: NBPP_LAUNCH_P3M(S0, W, 16); break;                 \
     }
     if (soft0) {
         if (wide) { NBPP_P3M_LANES(true, true) } else { NBPP_P3M_LANES(true, false) }
