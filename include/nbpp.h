@@ -107,7 +107,7 @@ enum {
     NBPP_OPT_DETERMINISTIC = 7,  /* 1 = never pick NBPP_KERNEL_DIRECT_SYMMETRIC by itself:
                                     results are then bitwise reproducible from run to run */
     NBPP_OPT_P3M_LANES_PER_TARGET = 8 /* P3M cell kernel: 0 = automatic (more lanes the fewer
-                                    targets), else 1, 2, 4 or 8                           */
+                                    targets), else 1, 2, 4, 8 or 16                       */
 };
 
 /*

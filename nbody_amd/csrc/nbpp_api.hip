@@ -407,9 +407,25 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     hipLaunchKernelGGL(k_ghost_count, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z, grid, cx, cy, cz,
                        count);
     CHK(exclusive_scan(static_cast<int>(ncell + 1), count, start, s));
-    int n_entries = 0;  // the one host read-back of the call: real + ghost entries
-    HIPCHK(hipMemcpyAsync(&n_entries, start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    // the one host read-back of the call: real + ghost entries and, for launches small enough for
+    // several lanes per target to be an option, the clustering measure of k_occupancy
+    int n_entries = 0;
+    double occupancy = 1.0;
+    if (n_tgt < (1 << 20)) {
+        CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
+        unsigned long long* occ = g.counter.as<unsigned long long>();
+        HIPCHK(hipMemsetAsync(occ, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_occupancy, dim3(static_cast<int>(std::min<long long>(256, cdiv(ncell, WG)))), dim3(WG), 0, s,
+                           static_cast<int>(ncell), count, start, occ);
+        unsigned long long host[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(host, occ, sizeof(host), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        n_entries = static_cast<int>(host[1]);
+        if (n_entries > 0) occupancy = static_cast<double>(host[0]) / n_entries;
+    } else {
+        HIPCHK(hipMemcpyAsync(&n_entries, start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
     if (n_entries < n_src) return fail(NBPP_ERR_HIP, "binning lost particles (%d < %d)", n_entries, n_src);
 
     // 2. scatter, canonical order inside each cell, records
@@ -474,9 +490,15 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     a.accepted = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
     a.k = k;
     const bool wide = n_entries >= (1 << 27);   // 32-byte records beyond 32-bit byte offsets
-    // lanes per target: enough lanes for every SIMD to hold several wavefronts
+    // lanes per target: more of them while the launch is too small to occupy the GPU.  Lanes of
+    // one target walk different rows, which costs the coalescing that neighbouring targets on the
+    // same row have, so on evenly spread particles one lane per target wins from about 2^16
+    // targets up (measured at 32^3 to 128^3: 32^3 best with 2-4 lanes, 48^3 and larger with 1).
+    // Clustered sets have a few very long targets and want more lanes for the same count
+    // (32^3 at a = 0.5 to 1: 8 lanes), hence the occupancy factor.
     int lanes = 1;
-    while (lanes < 8 && static_cast<long long>(n_tgt) * lanes < 400000) lanes *= 2;
+    const double enough = 65536.0 * std::min(std::max(occupancy, 1.0), 16.0);
+    while (lanes < 8 && static_cast<double>(n_tgt) * lanes < enough) lanes *= 2;
     if (g.opt_p3m_lanes == 1 || g.opt_p3m_lanes == 2 || g.opt_p3m_lanes == 4 || g.opt_p3m_lanes == 8 ||
         g.opt_p3m_lanes == 16)
         lanes = static_cast<int>(g.opt_p3m_lanes);

@@ -735,6 +735,28 @@ __global__ void k_ghost_count(int n, const double* __restrict__ x, const double*
     for_each_image(px, py, pz, g, [&](int cell, unsigned) { atomicAdd(&count[cell], 1); });
 }
 
+// out[0] += sum over cells of count^2 (out[0] zeroed beforehand); out[1] = number of entries.
+// sum(count^2) / entries is the mean occupancy of the cell an entry sits in: about 1.6 for one
+// particle per cell spread evenly, tens to hundreds once the particles have clustered.
+__global__ void __launch_bounds__(WG) k_occupancy(int ncell, const int* __restrict__ count,
+                                                  const int* __restrict__ start,
+                                                  unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long lds[WG / 64];
+    unsigned long long s = 0;
+    for (int c = blockIdx.x * WG + threadIdx.x; c < ncell; c += gridDim.x * WG) {
+        const unsigned long long k = static_cast<unsigned long long>(count[c]);
+        s += k * k;
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = lds[0] + lds[1] + lds[2] + lds[3];
+        if (t) atomicAdd(&out[0], t);
+        if (blockIdx.x == 0) out[1] = static_cast<unsigned long long>(start[ncell]);
+    }
+}
+
 // `fill` holds the cell counts of k_ghost_count and is counted down to zero, a cell's slots being
 // handed out from its last to its first; the within-cell order produced here is arbitrary and is
 // made deterministic by k_cell_canon / k_cell_canon_big afterwards.

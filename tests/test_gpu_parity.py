@@ -633,9 +633,9 @@ def test_overfull_cells_are_ordered_deterministically(lib, use_pm):
         assert np.array_equal(u, v)
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
 def test_p3m_lanes_per_target(lib, oracle, lanes):
-    """The cell kernel with 1, 2, 4 or 8 lanes sharing a target (automatic choice: more lanes the
+    """The cell kernel with 1, 2, 4, 8 or 16 lanes sharing a target (automatic choice: more lanes the
     fewer targets): same accepted pairs, same forces, and a sub-range of targets."""
     pos = datasets.clustered(20000, seed=lanes)
     m = datasets.masses(20000, equal=False)

@@ -34,7 +34,7 @@ lib = nbody_amd.load(device=0)
 lib.set_option(ffi.OPT_TIMING, 1)
 d = [torch.as_tensor(a, device="cuda:0") for a in pos] + [torch.full((n,), config.DM_PARTICLE_MASS, dtype=torch.float64, device="cuda:0")]
 acc = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
-for lanes in (1, 2, 4):
+for lanes in (0, 1, 2, 4, 8, 16):
     lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, lanes)
     for _ in range(3):
         lib.accumulate_device(p, *d, *acc)
