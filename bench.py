@@ -59,6 +59,9 @@ def cpu_baseline(p, pos, m, mode, budget_s=15.0):
 
 
 def main():
+    if os.environ.get("NBODY_BENCH_WATCHDOG"):   # seconds: dump every thread's stack and exit if still running
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["NBODY_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)

@@ -130,11 +130,13 @@ def force_evaluation_pairs(parts: SlicedParticles, mass_all: torch.Tensor,
             for r in range(parts.world):
                 work[c][r * parts.stride: r * parts.stride + parts.counts[r]] = \
                     full[c][parts.begins[r]: parts.begins[r] + parts.counts[r]]
-        out = torch.empty(parts.stride, dtype=x.dtype, device=parts.device)
-        try:
-            dist.reduce_scatter_tensor(out, work[c])
-        except RuntimeError:            # backends without reduce-scatter (gloo): all-reduce
+        if dist.get_backend() == "gloo":
+            # no usable reduce-scatter there (CPU tensors: not implemented; CUDA tensors: observed
+            # to block forever): all-reduce and keep the own slice
             dist.all_reduce(work[c])
             out = work[c][parts.rank * parts.stride: (parts.rank + 1) * parts.stride]
+        else:
+            out = torch.empty(parts.stride, dtype=x.dtype, device=parts.device)
+            dist.reduce_scatter_tensor(out, work[c])
         acc[c].copy_(out[: parts.count])
     return work
