@@ -32,6 +32,8 @@ config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
 p = config.pp_params()
 lib = nbody_amd.load(device=0)
 lib.set_option(ffi.OPT_TIMING, 1)
+if os.environ.get("P3M_PROBE_RADIUS"):   # search radius in cells (default 3)
+    lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, int(os.environ["P3M_PROBE_RADIUS"]))
 d = [torch.as_tensor(a, device="cuda:0") for a in pos] + [torch.full((n,), config.DM_PARTICLE_MASS, dtype=torch.float64, device="cuda:0")]
 acc = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
 for lanes in (0, 1, 2, 4, 8, 16):
