@@ -892,7 +892,7 @@ struct P3MArgs {
 constexpr int P3M_QCAP = 16;    // accepted-pair ring per lane (power of 2; 16 KiB LDS per workgroup)
 constexpr int P3M_DRAIN_UNROLL = 2;   // record fetches in flight per lane while draining
 constexpr int P3M_DRAIN = 8;   // entries every lane evaluates when some lane's ring is full
-constexpr int P3M_TRIP = 4;    // candidates a lane tests per trip of the filter loop (2 or 4)
+constexpr int P3M_TRIP = 4;    // candidates a lane tests per trip of the filter loop (2, 4 or 8)
 
 // One lane per target.  Two phases per lane, interleaved wave-wide:
 //   filter: walk the (2R+1)^2 runs, P3M_TRIP candidates per trip, and push the sorted position
@@ -921,7 +921,7 @@ __device__ __forceinline__ int load_word(const int* base, int idx) {   // idx < 
                                          (static_cast<uint32_t>(idx) << 2));
 }
 static_assert((P3M_QCAP & (P3M_QCAP - 1)) == 0 && P3M_DRAIN % P3M_DRAIN_UNROLL == 0 &&
-              P3M_QCAP % P3M_DRAIN_UNROLL == 0 && P3M_DRAIN >= P3M_TRIP && (P3M_TRIP == 2 || P3M_TRIP == 4),
+              P3M_QCAP % P3M_DRAIN_UNROLL == 0 && P3M_DRAIN >= P3M_TRIP && (P3M_TRIP == 2 || P3M_TRIP == 4 || P3M_TRIP == 8),
               "ring sizes");
 __device__ __forceinline__ int ring_slot(int i) { return i & (P3M_QCAP - 1); }
 
@@ -934,6 +934,16 @@ template <> struct p3m_fvec_load<2> {
     typedef unsigned vu __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ vf get(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
         return __builtin_bit_cast(vf, (vu)__builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+    }
+};
+template <> struct p3m_fvec_load<8> {
+    typedef float vf __attribute__((ext_vector_type(8)));
+    typedef float hf __attribute__((ext_vector_type(4)));
+    typedef unsigned vu __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vf get(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
+        const hf lo = __builtin_bit_cast(hf, (vu)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        const hf hi = __builtin_bit_cast(hf, (vu)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off == 0xfffffff0u ? off : off + 16u, 0, 0));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 };
 template <> struct p3m_fvec_load<4> {
