@@ -92,6 +92,15 @@ __device__ __forceinline__ size_t corner(const Cloud& c, int q, int N) {   // q 
     return (static_cast<size_t>(ix) * N + iy) * N + iz;
 }
 
+// Which WG-sized piece of the particle array this workgroup takes.  Workgroups go to the 8 XCDs
+// round-robin and every XCD has its own L2; neighbours in the particle order mostly touch the
+// same mesh cells, so within every group of 128 workgroups XCD k takes 16 consecutive pieces
+// (deposit at 256^3: 0.77 instead of 0.84 ms).
+__device__ __forceinline__ size_t xcd_piece() {
+    const size_t b = blockIdx.x, group = b / 128, in_group = b % 128;
+    return (group + 1) * 128 <= gridDim.x ? group * 128 + (in_group % 8) * 16 + in_group / 8 : b;
+}
+
 // rho += m * w / V.  The reference sums m * w and divides the finished mesh by the cell volume
 // (:85-92, :99); here every term is divided, which is the same to rounding and saves a pass.
 __global__ void __launch_bounds__(WG) k_cic_deposit(size_t n, const double* __restrict__ x,
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(WG) k_cic_deposit(size_t n, const double* __re
                                                     const double* __restrict__ z,
                                                     const double* __restrict__ m, double cell,
                                                     double cell_volume, int N, double* __restrict__ rho) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    const size_t i = xcd_piece() * WG + threadIdx.x;
     if (i >= n) return;
     const Cloud c = cloud_of(x[i], y[i], z[i], cell, N);
     double w[8];
@@ -162,7 +171,7 @@ __global__ void __launch_bounds__(WG) k_cic_interpolate(size_t n, const double* 
                                                         const double* __restrict__ gz,
                                                         double* __restrict__ ax, double* __restrict__ ay,
                                                         double* __restrict__ az) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    const size_t i = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;   // (xcd_piece() measured: no gain here)
     if (i >= n) return;
     const Cloud c = cloud_of(x[i], y[i], z[i], cell, N);
     double w[8];
