@@ -399,8 +399,36 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     grid.np = nside + 2 * R;
     grid.scale = nside / p->domain_size;
     grid.L = p->domain_size;
+    grid.keep_lo = 0;
+    grid.keep_len = nside;
     const long long ncell = 1LL * grid.np * grid.np * grid.np;
     if (ncell + 1 > 0x7fffffffLL) return fail(NBPP_ERR_RANGE, "search grid too large");
+    const bool all_targets = tgt_begin == 0 && n_tgt == n_src;
+
+    // 0. a slice of the particles as targets (one rank's share of a multi-GPU run): if the slice
+    // occupies only part of the box in x, only that slab and a halo of R cells need binning.
+    // The occupied x cells are read back (nside integers); the slab is the complement of their
+    // largest empty circular gap.
+    if (!all_targets && n_tgt > 0) {
+        CHK(g.blocksum.ensure(sizeof(int) * nside));
+        int* hist = g.blocksum.as<int>();
+        HIPCHK(hipMemsetAsync(hist, 0, sizeof(int) * nside, s));
+        hipLaunchKernelGGL(k_target_x_cells, dim3(cdiv(n_tgt, WG)), dim3(WG), 0, s, n_tgt, x + tgt_begin, grid, hist);
+        std::vector<int> occupied(nside);
+        HIPCHK(hipMemcpyAsync(occupied.data(), hist, sizeof(int) * nside, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        int best_start = 0, best_len = 0;      // longest run of empty cells on the circle
+        for (int c = 0; c < nside; ++c) {
+            if (occupied[c] == 0) continue;    // a run of empty cells starts after an occupied one
+            int len = 0;
+            while (len < nside && occupied[(c + 1 + len) % nside] == 0) ++len;
+            if (len > best_len) { best_len = len; best_start = (c + 1) % nside; }
+        }
+        if (best_len > 2 * R) {
+            grid.keep_lo = (best_start + best_len - R) % nside;        // R cells before the first occupied one
+            grid.keep_len = nside - best_len + 2 * R;
+        }
+    }
 
     // 1. positions into [0, L), histogram over real + ghost cells, offsets
     for (Buf& b : g.canon) CHK(b.ensure(sizeof(double) * n_src));
@@ -432,7 +460,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         HIPCHK(hipMemcpyAsync(&n_entries, start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    if (n_entries < n_src) return fail(NBPP_ERR_HIP, "binning lost particles (%d < %d)", n_entries, n_src);
+    if (n_entries < (grid.keep_len == nside ? n_src : n_tgt))
+        return fail(NBPP_ERR_HIP, "binning lost particles (%d entries)", n_entries);
 
     // 2. scatter, canonical order inside each cell, records
     CHK(g.src.order.ensure(sizeof(int) * n_entries));
@@ -459,7 +488,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // 3. list of targets in sorted order
     CHK(g.tgt.order.ensure(sizeof(int) * n_tgt));
     int* tlist = g.tgt.order.as<int>();
-    if (tgt_begin == 0 && n_tgt == n_src) {
+    if (all_targets) {
         // every real entry: one contiguous piece per column of the grid
         const int ncol = grid.np * grid.np;
         CHK(g.src.cell.ensure(sizeof(int) * (ncol + 1)));

@@ -702,7 +702,28 @@ struct GhostGrid {
     int nside;      // real cells per axis
     int R;          // ghost layers = search radius in cells
     int np;         // nside + 2R
+    // Sources are binned only if their x cell lies in the circular range [keep_lo, keep_lo +
+    // keep_len) of the nside cells: the x cells the targets occupy, widened by R on both sides.
+    // keep_len = nside keeps everything (every particle is a target, or the targets are spread
+    // over the whole box).  A rank of a multi-GPU run, whose targets are a slab, bins its slab
+    // and a halo instead of the whole box.
+    int keep_lo;
+    int keep_len;
 };
+
+__device__ __forceinline__ bool x_cell_kept(const GhostGrid& g, int ix) {
+    int d = ix - g.keep_lo;
+    d += d < 0 ? g.nside : 0;
+    return d < g.keep_len;
+}
+
+// occupied[ix] = 1 for the x cell of every target (array zeroed beforehand).  Plain stores of the
+// same value: millions of targets share a few dozen cells, and atomics on them would serialise.
+__global__ void k_target_x_cells(int n_tgt, const double* __restrict__ x, GhostGrid g, int* __restrict__ occupied) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tgt) return;
+    occupied[bin_coord(canonical(x[i], g.L), g.scale, g.nside)] = 1;
+}
 
 // Calls f(padded_cell_id, code) for every image of a particle at canonical (x, y, z).
 template <class F>
@@ -732,6 +753,7 @@ __global__ void k_ghost_count(int n, const double* __restrict__ x, const double*
     if (i >= n) return;
     const double px = canonical(x[i], g.L), py = canonical(y[i], g.L), pz = canonical(z[i], g.L);
     cx[i] = px; cy[i] = py; cz[i] = pz;
+    if (!x_cell_kept(g, bin_coord(px, g.scale, g.nside))) return;
     for_each_image(px, py, pz, g, [&](int cell, unsigned) { atomicAdd(&count[cell], 1); });
 }
 
@@ -766,6 +788,7 @@ __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const doubl
                                 int* __restrict__ entries, uint8_t* __restrict__ codes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (!x_cell_kept(g, bin_coord(x[i], g.scale, g.nside))) return;   // the same test as k_ghost_count's
     for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned code) {
         const int slot = start[cell] + atomicSub(&fill[cell], 1) - 1;
         entries[slot] = i;

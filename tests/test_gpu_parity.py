@@ -452,6 +452,46 @@ def test_128cubed_sampled_targets_and_momentum(lib, oracle):
         assert abs(np.sum(m * got[c])) < 1e-9 * typical
 
 
+@pytest.mark.parametrize("n_side,shift", [(40, 0.0), (40, 0.37), (64, 0.9)])
+def test_p3m_target_slabs_bin_only_their_slab(lib, oracle, n_side, shift):
+    """One rank's share of a multi-GPU P3M run: targets that are a contiguous index slice of a
+    lattice-ordered set occupy a slab in x, and only that slab plus a halo is binned.  Four and
+    seven slabs of a jittered lattice whose index order starts `shift` of the way through the box
+    (so that one slab straddles x = L), 64^3 with the two-cell search grid: forces of all slabs
+    against the oracle, accepted pairs of the slabs adding up to the count of the whole, and a
+    slab of a single lattice plane."""
+    import torch
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side)
+    roll = int(shift * n_side) * n_side * n_side               # whole x planes
+    pos = [np.ascontiguousarray(np.roll(c, -roll)) for c in pos]
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    m = np.full(n, config.DM_PARTICLE_MASS)
+    p = config.pp_params()
+    want = oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS)
+    total = oracle.count_within_cutoff(p, *pos)
+    x, y, z, mm = _t(pos + [m])
+    for world in (4, 7):
+        bounds = [r * n // world for r in range(world + 1)]
+        pieces, counted = [[], [], []], 0
+        for b, e in zip(bounds, bounds[1:]):
+            acc = [torch.zeros(e - b, dtype=torch.float64, device="cuda") for _ in range(3)]
+            lib.accumulate_device(p, x, y, z, mm, *acc, tgt_begin=b, n_tgt=e - b)
+            torch.cuda.synchronize()
+            assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
+            counted += lib.stats()["pairs_accepted"]
+            for c in range(3):
+                pieces[c].append(acc[c].cpu().numpy())
+        assert counted == total
+        assert normalised_error([np.concatenate(pc) for pc in pieces], want) < TOL
+    plane = n_side * n_side
+    b = 3 * plane
+    acc = [torch.zeros(plane, dtype=torch.float64, device="cuda") for _ in range(3)]
+    lib.accumulate_device(p, x, y, z, mm, *acc, tgt_begin=b, n_tgt=plane)
+    torch.cuda.synchronize()
+    assert normalised_error([a.cpu().numpy() for a in acc], [w[b:b + plane] for w in want]) < TOL
+
+
 def test_p3m_256cubed_sampled_targets_counts_and_momentum(lib, oracle):
     """N = 256^3 P3M short range with the mesh force on top (the whole force phase at the
     headline P3M size): sampled target slices against the oracle's sum over all 16.8 M sources,
