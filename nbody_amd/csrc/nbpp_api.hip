@@ -438,8 +438,10 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     int* count = g.count.as<int>();
     int* start = g.src.start.as<int>();
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
+    CHK(g.tgt.rank.ensure(sizeof(int) * n_src));
+    int* rank = g.tgt.rank.as<int>();
     hipLaunchKernelGGL(k_ghost_count, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z, grid, cx, cy, cz,
-                       count);
+                       count, rank);
     CHK(exclusive_scan(static_cast<int>(ncell + 1), count, start, s));
     // the one host read-back of the call: real + ghost entries and, for launches small enough for
     // several lanes per target to be an option, the clustering measure of k_occupancy
@@ -477,7 +479,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     float* fy = fx + f_stride;
     float* fz = fy + f_stride;
     hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
-                       start, count, entries, codes);
+                       start, count, rank, entries, codes);
     CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));   // scratch here, target flags / slots below
     CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
     CHK(canonical_order(static_cast<int>(ncell), n_entries, start, entries, g.src.cell.as<int>(),

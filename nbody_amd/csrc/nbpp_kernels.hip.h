@@ -745,16 +745,22 @@ __device__ __forceinline__ void for_each_image(double x, double y, double z, con
 }
 
 // Brings the positions into [0, L) (kept in cx, cy, cz for the passes after this one) and counts
-// every image's cell.
+// every image's cell.  What the counter of its own cell held when a particle arrived is kept as
+// the particle's rank there, so that k_ghost_scatter can place the real images without a second
+// round of atomics.
 __global__ void k_ghost_count(int n, const double* __restrict__ x, const double* __restrict__ y,
                               const double* __restrict__ z, GhostGrid g, double* __restrict__ cx,
-                              double* __restrict__ cy, double* __restrict__ cz, int* __restrict__ count) {
+                              double* __restrict__ cy, double* __restrict__ cz, int* __restrict__ count,
+                              int* __restrict__ rank) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double px = canonical(x[i], g.L), py = canonical(y[i], g.L), pz = canonical(z[i], g.L);
     cx[i] = px; cy[i] = py; cz[i] = pz;
     if (!x_cell_kept(g, bin_coord(px, g.scale, g.nside))) return;
-    for_each_image(px, py, pz, g, [&](int cell, unsigned) { atomicAdd(&count[cell], 1); });
+    for_each_image(px, py, pz, g, [&](int cell, unsigned code) {
+        if (code == 0u) rank[i] = atomicAdd(&count[cell], 1);
+        else atomicAdd(&count[cell], 1);
+    });
 }
 
 // out[0] += sum over cells of count^2 (out[0] zeroed beforehand); out[1] = number of entries.
@@ -779,18 +785,20 @@ __global__ void __launch_bounds__(WG) k_occupancy(int ncell, const int* __restri
     }
 }
 
-// `fill` holds the cell counts of k_ghost_count and is counted down to zero, a cell's slots being
-// handed out from its last to its first; the within-cell order produced here is arbitrary and is
-// made deterministic by k_cell_canon / k_cell_canon_big afterwards.
+// Real images go to the rank k_ghost_count noted.  Ghost cells (which hold ghost images only) are
+// filled by counting their counters in `fill` down to zero, a cell's slots being handed out from
+// its last to its first.  The within-cell order produced here is arbitrary and is made
+// deterministic by k_cell_canon / k_cell_canon_big afterwards.
 __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const double* __restrict__ y,
                                 const double* __restrict__ z, GhostGrid g,
                                 const int* __restrict__ start, int* __restrict__ fill,
+                                const int* __restrict__ rank,
                                 int* __restrict__ entries, uint8_t* __restrict__ codes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!x_cell_kept(g, bin_coord(x[i], g.scale, g.nside))) return;   // the same test as k_ghost_count's
     for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned code) {
-        const int slot = start[cell] + atomicSub(&fill[cell], 1) - 1;
+        const int slot = start[cell] + (code == 0u ? rank[i] : atomicSub(&fill[cell], 1) - 1);
         entries[slot] = i;
         codes[slot] = static_cast<uint8_t>(code);
     });
