@@ -29,6 +29,7 @@
 #include "ics.hpp"
 #include "integrator.hpp"
 #include "particles.hpp"
+#include "simulation.hpp"
 #include "snapshot.hpp"
 
 using namespace nbh;
@@ -285,155 +286,22 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (argc >= 4 && !std::strcmp(argv[1], "run")) {
+            // run <ini> <cycles> [snapshot directory (HDF5) or file prefix (raw) [diagnostics.csv
+            // directory [cycles between device-time samples]]]
             if (nbpp_init(0) != NBPP_OK) { std::printf("nbpp_init failed: %s\n", nbpp_last_error()); return 2; }
-            nbpp_set_option(NBPP_OPT_TIMING, 1);
             Config config;
             config.load(argv[2]);
             config.MAX_CYCLES = std::atoi(argv[3]);
-            Cosmology cosmo;
-            ZeldovichField field;
-            ParticleSystem dm = initialize_particles(config, cosmo, &field);
-            DeviceEngine engine(config, dm, config.USE_HYDRO ? &field : nullptr);
-            // device times are sampled on the cycles that print them, and on the last one of a run
-            // bounded by its cycle count (optional sixth argument: another sampling interval, 1 =
-            // every cycle)
-            engine.timing_every = argc >= 7 ? std::atoi(argv[6])
-                                            : std::max(1, std::min(config.DEBUG_INFO_EVERY_CYCLES, config.MAX_CYCLES));
-            auto report = [&](const char* when) {
-                ParticleSystem now(config);
-                engine.download(now);
-                std::printf("%s: cycle %ld a=%.17g dt=%.17g max|a|^2=%.17g\n", when, engine.cycle_count,
-                            engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq);
-                if (now.num_particles)
-                    std::printf("%s: p0 acc %.17g %.17g %.17g\n", when, now.acc_x[0], now.acc_y[0], now.acc_z[0]);
-                std::vector<double> gas[9];
-                engine.download_gas(gas);
-                if (!gas[0].empty()) {
-                    double mass = 0.0, energy = 0.0;
-                    for (double v : gas[0]) mass += v;
-                    for (double v : gas[4]) energy += v;
-                    std::printf("%s: gas mass %.17g energy %.17g\n", when, mass * config.CELL_VOLUME,
-                                energy * config.CELL_VOLUME);
-                }
-            };
-            report("initial");
-            // the first force phase also pays for set-up (FFT plans, buffers): keep it out of the averages
-            engine.pp_ms = engine.pm_ms = engine.gas_ms = 0.0;
-            engine.timed_force_calls = engine.timed_steps = 0;
-            // Snapshots with the reference's cadence (src/engine.cpp:28-33, :56-67): one at the start,
-            // one whenever a passes next_output_a, one at the end.  If the fourth argument names a
-            // directory: snapshot_%04d.hdf5 files in it, the reference's layout (snapshot.hpp).
-            // Otherwise it is a file prefix for raw little-endian doubles:
-            // {n, mesh, a, t, L, use_hydro}, x, y, z, mass[n], then gas density and energy [mesh^3]
-            // with hydro.
-            const char* snap_prefix = argc >= 5 ? argv[4] : nullptr;
-            std::unique_ptr<SnapshotWriter> hdf5;
-            if (snap_prefix && std::filesystem::is_directory(snap_prefix))
-                hdf5.reset(new SnapshotWriter(snap_prefix, config));
-            int snapshot_count = 0;
-            double next_output_a = config.START_A + config.SAVE_HDF5_EVERY_DELTA_A;
-            auto save_snapshot = [&]() {
-                if (!snap_prefix) return;
-                ParticleSystem now(config);
-                engine.download(now);
-                std::vector<double> gas[9];
-                engine.download_gas(gas);
-                if (hdf5) {
-                    hdf5->save_snapshot(snapshot_count++, engine.cycle_count, now, gas, engine.cosmo.total_time,
-                                        engine.cosmo.scale_factor, config);
-                    return;
-                }
-                char name[1024];
-                std::snprintf(name, sizeof(name), "%s_%04d.bin", snap_prefix, snapshot_count++);
-                FILE* f = std::fopen(name, "wb");
-                if (!f) throw std::runtime_error("cannot open snapshot file");
-                const double head[6] = {static_cast<double>(now.num_particles), static_cast<double>(config.MESH_SIZE),
-                                        engine.cosmo.scale_factor, engine.cosmo.total_time, config.DOMAIN_SIZE,
-                                        config.USE_HYDRO ? 1.0 : 0.0};
-                std::fwrite(head, sizeof(double), 6, f);
-                for (auto* v : {&now.pos_x, &now.pos_y, &now.pos_z, &now.mass})
-                    std::fwrite(v->data(), sizeof(double), v->size(), f);
-                if (config.USE_HYDRO) {
-                    std::fwrite(gas[0].data(), sizeof(double), gas[0].size(), f);
-                    std::fwrite(gas[4].data(), sizeof(double), gas[4].size(), f);
-                }
-                std::fclose(f);
-            };
-            if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0) save_snapshot();
-            // diagnostics.csv in the directory given as the fifth argument, with the reference's
-            // columns and cadence (src/engine.cpp:24-26, :69-75)
-            Logger logger(argc >= 6 ? argv[5] : "/nonexistent");
-            long logged_cycle = 0, logged_calls = 0, logged_steps = 0;
-            double logged_ms[3] = {0.0, 0.0, 0.0}, last_avg[3] = {0.0, 0.0, 0.0};
-            auto logged_wall = std::chrono::steady_clock::now();
-            auto log_diagnostics = [&]() {
-                if (!logger.is_open()) return;
-                ParticleSystem now(config);
-                engine.download(now);
-                std::vector<double> gas[9], total_rho, phi;
-                engine.download_gas(gas);
-                engine.download_mesh_solve(total_rho, phi);
-                Diagnostics d = compute_diagnostics(config, now, gas, total_rho, phi, engine.cosmo,
-                                                    engine.cfl_timestep(), engine.gravity_timestep(), engine.current_dt);
-                d.cycle = engine.cycle_count;
-                const long cycles = engine.cycle_count - logged_cycle;
-                const auto wall_now = std::chrono::steady_clock::now();
-                if (cycles > 0) {                                    // averages since the last line
-                    d.avg_step = std::chrono::duration<double>(wall_now - logged_wall).count() / cycles;
-                    // device times: averages over the cycles since the last line that were timed
-                    // (none timed, as can happen for the last line of a run: the averages before it)
-                    const long calls = engine.timed_force_calls - logged_calls;
-                    const long steps = engine.timed_steps - logged_steps;
-                    if (calls > 0) {
-                        last_avg[0] = (engine.pm_ms - logged_ms[0]) * 1e-3 / calls;
-                        last_avg[1] = (engine.pp_ms - logged_ms[1]) * 1e-3 / calls;
-                    }
-                    if (steps > 0) last_avg[2] = (engine.gas_ms - logged_ms[2]) * 1e-3 / steps;
-                    d.avg_pm = last_avg[0];
-                    d.avg_pp = last_avg[1];
-                    d.avg_hydro = last_avg[2];
-                }
-                logger.log(d);
-                logged_cycle = engine.cycle_count;
-                logged_ms[0] = engine.pm_ms; logged_ms[1] = engine.pp_ms; logged_ms[2] = engine.gas_ms;
-                logged_calls = engine.timed_force_calls; logged_steps = engine.timed_steps;
-                logged_wall = std::chrono::steady_clock::now();
-            };
-            log_diagnostics();
-            const auto t0 = std::chrono::steady_clock::now();
-            // engine.run() (src/engine.cpp:78-91) unrolled, to log like the reference does every
-            // DEBUG_INFO_EVERY_CYCLES cycles (src/engine.cpp:69-75)
+            RunOptions options;
+            if (argc >= 5) options.snapshot_target = argv[4];
+            if (argc >= 6) options.log_dir = argv[5];
+            if (argc >= 7) options.timing_every = std::atoi(argv[6]);
+            Simulation sim(config, options);
+            sim.report("initial");
             std::signal(SIGINT, on_sigint);
-            while (engine.needs_more_cycles && !g_stop_requested) {
-                engine.step();
-                if (config.DEBUG_INFO_EVERY_CYCLES > 0 && engine.cycle_count % config.DEBUG_INFO_EVERY_CYCLES == 0) {
-                    nbpp_stats ps{};
-                    nbpp_get_stats(&ps);
-                    std::printf("cycle %ld: a=%.6f dt=%.4e max|a|^2=%.4e | last PP call %.3f ms (binning %.3f, pairs %.3f), %.4g accepted pairs (%.1f G/s)\n",
-                                engine.cycle_count, engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq,
-                                ps.total_ms, ps.prepare_ms, ps.pair_kernel_ms, static_cast<double>(ps.pairs_accepted),
-                                ps.total_ms > 0 ? ps.pairs_accepted / ps.total_ms * 1e-6 : 0.0);
-                    std::fflush(stdout);
-                }
-                const bool last_cycle = !engine.needs_more_cycles || g_stop_requested;
-                if (config.DEBUG_INFO_EVERY_CYCLES > 0 &&
-                    (last_cycle || engine.cycle_count % config.DEBUG_INFO_EVERY_CYCLES == 0))
-                    log_diagnostics();
-                const bool must_save = engine.cosmo.scale_factor >= next_output_a;
-                if (config.SAVE_HDF5_EVERY_DELTA_A > 0.0 && (last_cycle || must_save)) {
-                    save_snapshot();
-                    while (next_output_a <= engine.cosmo.scale_factor) next_output_a += config.SAVE_HDF5_EVERY_DELTA_A;
-                }
-            }
-            const ExitStatus st = g_stop_requested ? ExitStatus::UserAborted
-                                  : engine.cycle_count >= config.MAX_CYCLES ? ExitStatus::ReachedMaxCycles
-                                                                            : ExitStatus::ReachedMaxScaleFactor;
-            const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            report("final");
-            std::printf("timing: %ld cycles, %.3f ms/cycle wall; PP %.3f, mesh %.3f, hydro sweeps %.3f ms/cycle (device, %ld timed cycles); exit=%d\n",
-                        engine.cycle_count, wall_ms / std::max(1L, engine.cycle_count),
-                        engine.pp_ms / std::max(1L, engine.timed_force_calls), engine.pm_ms / std::max(1L, engine.timed_force_calls),
-                        engine.gas_ms / std::max(1L, engine.timed_steps), engine.timed_steps, static_cast<int>(st));
+            const ExitStatus st = sim.run(&g_stop_requested);
+            sim.report("final");
+            sim.print_timing(st);
             nbgas_shutdown();
             nbpm_shutdown();
             nbpp_shutdown();
