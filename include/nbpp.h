@@ -140,9 +140,10 @@ int nbpp_accumulate(const nbpp_params* p, size_t n,
  * sources.  Targets are the sub-range [tgt_begin, tgt_begin + n_tgt) of the sources
  * (the i-partition of a multi-GPU run: each rank passes the all-gathered sources and
  * its own slice).  ax,ay,az are DEVICE pointers of length n_tgt, indexed by
- * i - tgt_begin, accumulated into.  Work is enqueued on `stream` (a hipStream_t, or
- * NULL for the library's own stream); the call returns after enqueueing unless
- * NBPP_OPT_TIMING is on.
+ * i - tgt_begin, accumulated into.  Work is enqueued on `stream` (a hipStream_t; NULL is the
+ * HIP null stream, as for every HIP call) and is ordered like any other work on that stream; the
+ * host returns once the pair kernel is queued (the P3M path waits once in between, for the number
+ * of cell-list entries), or when it has finished if NBPP_OPT_TIMING is on.
  */
 int nbpp_accumulate_device(const nbpp_params* p, size_t n_src,
                            const double* x, const double* y, const double* z,
@@ -173,6 +174,11 @@ int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n,
  * nbpp_max_accel_sq_device
  *                       max(1e-9, max_i ax^2+ay^2+az^2) -> *out_host (blocking)
  *                                                              src/integrator.cpp:200-213
+ * nbpp_add_device       a += b, per component                  src/particles.cpp:362-364
+ *                       The final `acc[i] += sum` of compute_pp_forces for a caller that let the
+ *                       short-range sums accumulate into arrays of their own (from zero) while
+ *                       the mesh force was being computed on another stream: mesh + sum is the
+ *                       same single rounding as the reference's mesh += sum.
  */
 int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz,
                      const double* ax, const double* ay, const double* az,
@@ -182,6 +188,8 @@ int nbpp_drift_device(size_t n, double* x, double* y, double* z,
                       double dt, double domain_size, void* stream);
 int nbpp_max_accel_sq_device(size_t n, const double* ax, const double* ay,
                              const double* az, double* out_host, void* stream);
+int nbpp_add_device(size_t n, double* ax, double* ay, double* az,
+                    const double* bx, const double* by, const double* bz, void* stream);
 
 #ifdef __cplusplus
 }

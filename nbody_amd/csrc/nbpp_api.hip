@@ -699,7 +699,7 @@ int nbpp_accumulate_device(const nbpp_params* p, size_t n_src, const double* x, 
     if (!x || !y || !z || !m || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
     std::lock_guard<std::mutex> lock(g_mu);
     HIPCHK(hipSetDevice(g.device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
     return compute_on_device(p, n_src, x, y, z, m, tgt_begin, n_tgt, ax, ay, az, s);
 }
 
@@ -715,7 +715,7 @@ int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n, const double* x
     if (!x || !y || !z || !m || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
     std::lock_guard<std::mutex> lock(g_mu);
     HIPCHK(hipSetDevice(g.device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
     return compute_on_device(p, n, x, y, z, m, 0, n, ax, ay, az, s, part, n_parts);
 }
 
@@ -762,6 +762,19 @@ int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const doubl
     return NBPP_OK;
 }
 
+int nbpp_add_device(size_t n, double* ax, double* ay, double* az, const double* bx,
+                    const double* by, const double* bz, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    if (n == 0) return NBPP_OK;
+    if (!ax || !ay || !az || !bx || !by || !bz) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
+    const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
+    hipLaunchKernelGGL(k_add, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz);
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
 int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz, const double* ax,
                      const double* ay, const double* az, double dt, double scale_factor,
                      double hubble, void* stream) {
@@ -769,7 +782,7 @@ int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz, const double*
     if (n == 0) return NBPP_OK;
     if (!vx || !vy || !vz || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
     HIPCHK(hipSetDevice(g.device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
     const double a3 = scale_factor * scale_factor * scale_factor;  // src/integrator.cpp:169
     const double dt_over_a3 = dt / a3;                             // :170
     const double dt_2H = dt * 2.0 * hubble;                        // :171
@@ -788,7 +801,7 @@ int nbpp_drift_device(size_t n, double* x, double* y, double* z, const double* v
     if (!x || !y || !z || !vx || !vy || !vz) return fail(NBPP_ERR_ARG, "NULL array pointer");
     if (!(domain_size > 0.0)) return fail(NBPP_ERR_ARG, "domain_size must be positive");
     HIPCHK(hipSetDevice(g.device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
     const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
     hipLaunchKernelGGL(k_drift, dim3(blocks), dim3(WG), 0, s, n, x, y, z, vx, vy, vz, dt,
                        domain_size, 1.0 / domain_size);  // inv_domain: src/integrator.cpp:184
@@ -805,7 +818,7 @@ int nbpp_max_accel_sq_device(size_t n, const double* ax, const double* ay, const
     if (!ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
     std::lock_guard<std::mutex> lock(g_mu);
     HIPCHK(hipSetDevice(g.device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g.stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
     const int blocks = std::min(1024, cdiv(static_cast<long long>(n), WG));
     CHK(g.blockmax.ensure(sizeof(double) * blocks));
     hipLaunchKernelGGL(k_max_accel_sq, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az,

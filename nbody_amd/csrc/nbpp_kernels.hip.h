@@ -1203,6 +1203,18 @@ __global__ void k_kick(size_t n, double* __restrict__ vx, double* __restrict__ v
     }
 }
 
+// a += b                                                          src/particles.cpp:362-364
+__global__ void k_add(size_t n, double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
+                      const double* __restrict__ bx, const double* __restrict__ by,
+                      const double* __restrict__ bz) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        ax[i] = __dadd_rn(ax[i], bx[i]);
+        ay[i] = __dadd_rn(ay[i], by[i]);
+        az[i] = __dadd_rn(az[i], bz[i]);
+    }
+}
+
 // x += v*dt ; x -= L*floor(x/L)                                  src/integrator.cpp:183-198
 __global__ void k_drift(size_t n, double* __restrict__ x, double* __restrict__ y,
                         double* __restrict__ z, const double* __restrict__ vx,

@@ -17,7 +17,7 @@ OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SE
 
 EXPORTS = (
     "nbpp_init", "nbpp_shutdown", "nbpp_last_error", "nbpp_set_option", "nbpp_get_stats",
-    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device",
+    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device", "nbpp_add_device",
     "nbpp_max_accel_sq_device",
 )
 
@@ -93,6 +93,7 @@ class Library:
         L.nbpp_accumulate_pairs_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 4 + [
             C.c_int, C.c_int] + [_DP] * 3 + [C.c_void_p]
         L.nbpp_kick_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 3 + [C.c_void_p]
+        L.nbpp_add_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_void_p]
         L.nbpp_drift_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 2 + [C.c_void_p]
         L.nbpp_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
         self._inited = False
@@ -149,6 +150,11 @@ class Library:
             _dev(ax), _dev(ay), _dev(az), C.c_void_p(stream or 0)))
 
     # caller contract ---------------------------------------------------------------
+    def add_device(self, a, b, stream=None):
+        """a += b per component (nbpp_add_device)."""
+        self._check(self.lib.nbpp_add_device(a[0].numel(), _dev(a[0]), _dev(a[1]), _dev(a[2]),
+                                             _dev(b[0]), _dev(b[1]), _dev(b[2]), C.c_void_p(stream or 0)))
+
     def kick_device(self, v, a, dt, scale_factor, hubble, stream=None):
         self._check(self.lib.nbpp_kick_device(v[0].numel(), _dev(v[0]), _dev(v[1]), _dev(v[2]),
                                               _dev(a[0]), _dev(a[1]), _dev(a[2]), dt,

@@ -36,7 +36,17 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
     }
     int device = 0;
     hip_check(hipGetDevice(&device), "hipGetDevice");
+    // One stream of the engine's own for everything: the three libraries would otherwise each fall
+    // back to a default of their own (libnbpp to a private non-blocking stream, the others to the
+    // null stream), with nothing ordering one library's kernels after another's.
+    hip_check(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&main_), hipStreamNonBlocking), "hipStreamCreate");
     for (void*& e : ev_) hip_check(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)), "hipEventCreate");
+    if (config_.USE_PM && config_.USE_PP && n_) {
+        hip_check(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&pp_stream_), hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pos_), hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pp_), hipEventDisableTiming), "hipEventCreate");
+        for (double*& a : pp_acc_) hip_check(hipMalloc(reinterpret_cast<void**>(&a), sizeof(double) * n_), "hipMalloc");
+    }
     const bool meshes = config_.USE_PM || config_.USE_HYDRO;
     if (meshes) {
         nbpm_check(nbpm_init(device));
@@ -52,7 +62,7 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
         nbgas_check(nbgas_init(device));
         for (double*& m : gas_) hip_check(hipMalloc(reinterpret_cast<void**>(&m), sizeof(double) * cells_), "hipMalloc");
         const nbpm_params mp = config_.mesh_params();
-        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], nullptr));
+        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], main_));
         // the displacement field is only needed now: stage it in the gravity meshes
         const std::vector<double>* disp[3] = {&field->dx, &field->dy, &field->dz};
         for (int c = 0; c < 3; ++c)
@@ -65,15 +75,22 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
         const nbgas_state gs = gas_state();
         nbgas_check(nbgas_initialize_device(&gp, &gs, mesh_[0], mesh_[2], mesh_[3], mesh_[4], mass_ratio,
                                             cosmo.hubble_param, field->f, config_.STANDING_PARTICLES ? 1 : 0, u0,
-                                            nullptr));
+                                            main_));
     }
     compute_accelerations();
     current_dt = next_timestep();                                            // src/engine.cpp:16-22
 }
 
 DeviceEngine::~DeviceEngine() {
+    (void)hipDeviceSynchronize();
     for (void* e : ev_)
         if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    if (ev_pos_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_pos_));
+    if (ev_pp_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_pp_));
+    if (pp_stream_) (void)hipStreamDestroy(static_cast<hipStream_t>(pp_stream_));
+    if (main_) (void)hipStreamDestroy(static_cast<hipStream_t>(main_));
+    for (double* p : pp_acc_)
+        if (p) (void)hipFree(p);
     for (double* p : dev_)
         if (p) (void)hipFree(p);
     for (double* p : gas_)
@@ -87,24 +104,25 @@ nbgas_state DeviceEngine::gas_state() const {
 }
 
 void DeviceEngine::compute_accelerations() {
+    hipStream_t ms = static_cast<hipStream_t>(main_);
     if (config_.USE_PM || config_.USE_HYDRO) {                               // :239-245
         // bin_and_assign_mass, total density, Poisson solve; the gas kick reads the meshes too
         const nbpm_params mp = config_.mesh_params();
-        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), nullptr), "event");
-        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], nullptr));
+        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), ms), "event");
+        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], main_));
         const double* source = mesh_[0];
         if (config_.USE_HYDRO) {                                             // :57-59
             const nbgas_params gp = config_.gas_params();
             const nbgas_state gs = gas_state();
-            nbgas_check(nbgas_total_density_device(&gp, &gs, mesh_[0], mesh_[1], nullptr));
+            nbgas_check(nbgas_total_density_device(&gp, &gs, mesh_[0], mesh_[1], main_));
             source = mesh_[1];
         }
-        nbpm_check(nbpm_solve_device(&mp, source, mesh_[2], mesh_[3], mesh_[4], nullptr));
+        nbpm_check(nbpm_solve_device(&mp, source, mesh_[2], mesh_[3], mesh_[4], main_));
         if (config_.USE_PM)
             nbpm_check(nbpm_interpolate_device(&mp, n_, dev_[0], dev_[1], dev_[2], mesh_[2], mesh_[3], mesh_[4],
-                                               dev_[6], dev_[7], dev_[8], nullptr));
+                                               dev_[6], dev_[7], dev_[8], main_));
         if (timed_) {
-            hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), nullptr), "event");
+            hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), ms), "event");
             hip_check(hipEventSynchronize(static_cast<hipEvent_t>(ev_[1])), "event");
             float ms = 0.0f;
             hip_check(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(ev_[0]), static_cast<hipEvent_t>(ev_[1])), "event");
@@ -113,25 +131,41 @@ void DeviceEngine::compute_accelerations() {
     }
     if (!config_.USE_PM) {                                                   // :246-251
         for (int c = 6; c < 9; ++c)
-            hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, nullptr), "zero acc");
-        hip_check(hipStreamSynchronize(nullptr), "sync");
+            hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, ms), "zero acc");
+        hip_check(hipStreamSynchronize(ms), "sync");
     }
-    if (config_.USE_PP && n_) {                                              // :254-258
+    const bool overlap = overlap_forces && !timed_ && pp_stream_ && pos_event_recorded_ && config_.USE_PM &&
+                         config_.USE_PP && n_;
+    if (overlap) {
+        // everything above is queued on the main stream and not waited for; the short-range force
+        // starts on its own stream as soon as the drift has finished
+        hipStream_t pps = static_cast<hipStream_t>(pp_stream_);
+        const nbpp_params p = config_.pp_params();
+        hip_check(hipStreamWaitEvent(pps, static_cast<hipEvent_t>(ev_pos_), 0), "wait");
+        for (double* a : pp_acc_) hip_check(hipMemsetAsync(a, 0, sizeof(double) * n_, pps), "zero");
+        nbpp_check(nbpp_set_option(NBPP_OPT_TIMING, 0));
+        nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_, pp_acc_[0], pp_acc_[1],
+                                          pp_acc_[2], pp_stream_));
+        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pp_), pps), "event");
+        hip_check(hipStreamWaitEvent(ms, static_cast<hipEvent_t>(ev_pp_), 0), "wait");
+        nbpp_check(nbpp_add_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2], main_));
+    } else if (config_.USE_PP && n_) {                                       // :254-258
         const nbpp_params p = config_.pp_params();
         nbpp_check(nbpp_set_option(NBPP_OPT_TIMING, timed_ ? 1 : 0));
         nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_,
-                                          dev_[6], dev_[7], dev_[8], nullptr));
+                                          dev_[6], dev_[7], dev_[8], main_));
         nbpp_stats st;
         if (timed_ && nbpp_get_stats(&st) == NBPP_OK) pp_ms += st.total_ms;
     }
+    pos_event_recorded_ = false;
     if (timed_) ++timed_force_calls;
     if (!config_.STANDING_PARTICLES) {                                       // :261-262
-        nbpp_check(nbpp_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, nullptr));
+        nbpp_check(nbpp_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, main_));
     } else {                                                                 // :263-269
-        nbpp_check(nbpp_max_accel_sq_device(0, nullptr, nullptr, nullptr, &max_accel_sq, nullptr));
+        nbpp_check(nbpp_max_accel_sq_device(0, nullptr, nullptr, nullptr, &max_accel_sq, main_));
         for (int c = 6; c < 9; ++c)
-            hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, nullptr), "zero acc");
-        hip_check(hipStreamSynchronize(nullptr), "sync");
+            hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, ms), "zero acc");
+        hip_check(hipStreamSynchronize(ms), "sync");
         max_accel_sq = 1e-9;
     }
 }
@@ -146,7 +180,7 @@ double DeviceEngine::cfl_timestep() {
     if (config_.USE_HYDRO) {
         const nbgas_params gp = config_.gas_params();
         const nbgas_state gs = gas_state();
-        nbgas_check(nbgas_cfl_timestep_device(&gp, &gs, &dt_cfl, nullptr));
+        nbgas_check(nbgas_cfl_timestep_device(&gp, &gs, &dt_cfl, main_));
     }
     return dt_cfl;
 }
@@ -167,11 +201,13 @@ void DeviceEngine::download_mesh_solve(std::vector<double>& total_rho, std::vect
     hip_check(hipMemcpy(total_rho.data(), source, sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
     // the potential is staged through the dark-matter density mesh, which the next force phase rebuilds
     const nbpm_params mp = config_.mesh_params();
-    nbpm_check(nbpm_potential_device(&mp, mesh_[0], nullptr));
+    nbpm_check(nbpm_potential_device(&mp, mesh_[0], main_));
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(main_)), "sync");
     hip_check(hipMemcpy(phi.data(), mesh_[0], sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
 }
 
 void DeviceEngine::step() {
+    hipStream_t ms = static_cast<hipStream_t>(main_);
     timed_ = timing_every > 0 && (cycle_count + 1) % timing_every == 0;
     const double dt = current_dt;
     const nbgas_params gp = config_.gas_params();
@@ -179,24 +215,28 @@ void DeviceEngine::step() {
     update_cosmology(cosmo, config_);                                                   // integrator.cpp:216
     if (config_.USE_HYDRO)                                                              // :219-220
         nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,
-                                      cosmo.hubble_param, nullptr));
+                                      cosmo.hubble_param, main_));
     nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
-                                cosmo.scale_factor, cosmo.hubble_param, nullptr));      // :221
+                                cosmo.scale_factor, cosmo.hubble_param, main_));      // :221
     nbpp_check(nbpp_drift_device(n_, dev_[0], dev_[1], dev_[2], dev_[3], dev_[4], dev_[5], dt,
-                                 config_.DOMAIN_SIZE, nullptr));                        // :224
+                                 config_.DOMAIN_SIZE, main_));                        // :224
+    if (pp_stream_ && overlap_forces && !timed_) {
+        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pos_), ms), "event");
+        pos_event_recorded_ = true;
+    }
     if (config_.USE_HYDRO) {                                                            // :227-230
-        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), nullptr), "event");
-        nbgas_check(nbgas_hydro_step_device(&gp, &gs, dt, nullptr));
-        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), nullptr), "event");
+        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), ms), "event");
+        nbgas_check(nbgas_hydro_step_device(&gp, &gs, dt, main_));
+        if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), ms), "event");
     }
     cosmo.total_time += dt;                                                             // :233
     update_cosmology(cosmo, config_);                                                   // :234
     compute_accelerations();                                                            // :236-269
     if (config_.USE_HYDRO)                                                              // :272-273
         nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,
-                                      cosmo.hubble_param, nullptr));
+                                      cosmo.hubble_param, main_));
     nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
-                                cosmo.scale_factor, cosmo.hubble_param, nullptr));      // :274
+                                cosmo.scale_factor, cosmo.hubble_param, main_));      // :274
     ++cycle_count;
     if (timed_) ++timed_steps;
     if (config_.USE_HYDRO && timed_) {

@@ -55,6 +55,12 @@ class DeviceEngine {
     double pp_ms = 0.0;                  // device time of the timed PP force calls
     double pm_ms = 0.0;                  // device time of the timed mesh force calls
     double gas_ms = 0.0;                 // device time of the timed gas sweeps
+    // On cycles that are not timed, the short-range force runs on a stream of its own (into
+    // arrays of its own, from zero) while the gas sweeps and the mesh force run on the main one;
+    // the two are added at the end, which rounds exactly as accumulating onto the mesh force does
+    // (src/particles.cpp:362-364).  The pair kernel is bound by instruction issue and ends in a
+    // tail of few long wavefronts; the mesh and gas kernels are bound by memory and fill in.
+    bool overlap_forces = true;
 
    private:
     void compute_accelerations();        // src/integrator.cpp:236-269
@@ -68,6 +74,12 @@ class DeviceEngine {
     bool stop_requested_ = false;
     bool timed_ = true;                  // the force phase / cycle in flight is being timed
     void* ev_[4] = {};                   // hipEvent_t: mesh begin/end, gas begin/end
+    void* main_ = nullptr;               // hipStream_t (non-blocking) every call of the step is queued on
+    void* pp_stream_ = nullptr;          // hipStream_t (non-blocking) of the overlapped short-range force
+    void* ev_pos_ = nullptr;             // positions of this cycle are final (recorded after the drift)
+    void* ev_pp_ = nullptr;              // short-range sums complete
+    bool pos_event_recorded_ = false;
+    double* pp_acc_[3] = {};             // short-range sums of the overlapped path
 };
 
 }  // namespace nbh

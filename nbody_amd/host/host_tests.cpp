@@ -296,6 +296,7 @@ int main(int argc, char** argv) {
             if (argc >= 5) options.snapshot_target = argv[4];
             if (argc >= 6) options.log_dir = argv[5];
             if (argc >= 7) options.timing_every = std::atoi(argv[6]);
+            if (std::getenv("NBODY_NO_OVERLAP")) options.overlap_forces = false;   // A/B switch
             Simulation sim(config, options);
             sim.report("initial");
             std::signal(SIGINT, on_sigint);

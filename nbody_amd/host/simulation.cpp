@@ -15,6 +15,7 @@ Simulation::Simulation(const Config& config, const RunOptions& options) : config
     ZeldovichField field;
     ParticleSystem dm = initialize_particles(config_, cosmo, &field);
     engine_.reset(new DeviceEngine(config_, dm, config_.USE_HYDRO ? &field : nullptr));
+    engine_->overlap_forces = options_.overlap_forces;
     engine_->timing_every = options_.timing_every >= 0
                                 ? options_.timing_every
                                 : std::max(1, std::min(config_.DEBUG_INFO_EVERY_CYCLES, config_.MAX_CYCLES));

@@ -33,6 +33,8 @@ struct RunOptions {
     int timing_every = -1;
     // "cycle N: ..." progress lines every DEBUG_INFO_EVERY_CYCLES cycles
     bool progress = true;
+    // DeviceEngine::overlap_forces
+    bool overlap_forces = true;
 };
 
 class Simulation {
