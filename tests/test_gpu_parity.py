@@ -398,6 +398,20 @@ def test_device_entry_target_slices(lib, oracle, use_pm):
     assert normalised_error(got, want) < TOL
 
 
+def test_add_device_is_one_rounding_per_component(lib):
+    """nbpp_add_device: a += b, what compute_pp_forces ends with (src/particles.cpp:362-364)."""
+    import torch
+    rng = np.random.default_rng(3)
+    a = [rng.standard_normal(5001) * 10.0 ** rng.integers(-8, 8, 5001) for _ in range(3)]
+    b = [rng.standard_normal(5001) * 10.0 ** rng.integers(-8, 8, 5001) for _ in range(3)]
+    ta, tb = _t(a), _t(b)
+    lib.add_device(ta, tb)
+    torch.cuda.synchronize()
+    for c in range(3):
+        assert np.array_equal(ta[c].cpu().numpy(), a[c] + b[c])
+        assert np.array_equal(tb[c].cpu().numpy(), b[c])
+
+
 def test_kick_drift_max_exact(lib, oracle):
     import torch
     rng = np.random.default_rng(2)
