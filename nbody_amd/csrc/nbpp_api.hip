@@ -86,7 +86,7 @@ struct Ctx {
     Buf host_in[4], host_acc[3];      // staging for the host-pointer entry point
     Buf canon[3];                     // P3M: positions brought into [0, L)
     Buf blockmax, counter, massinfo;
-    Buf biglist;                      // cells too full for the one-thread sort: count, ids
+    Buf biglist;                      // cells too full for the one-thread sort: two lists of count, ids
     Buf ghostcode;                    // P3M: image code of every sorted entry
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
             opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0;
@@ -138,13 +138,18 @@ PairConsts make_consts(const nbpp_params* p) {
     return k;
 }
 
-// Members of every cell into ascending entry order (k_cell_canon, k_cell_canon_big).
+// Members of every cell into ascending entry order (k_cell_canon, k_cell_canon_mid, k_cell_canon_big).
 int canonical_order(int ncell, int n_entries, const int* start, int* order, int* tmp_val, int* tmp_rank,
                     hipStream_t s) {
-    CHK(g.biglist.ensure(sizeof(int) * (static_cast<size_t>(n_entries) / CANON_SMALL + 2)));
-    int* big = g.biglist.as<int>();
+    const size_t n_mid = static_cast<size_t>(n_entries) / (CANON_TINY + 1) + 2;
+    const size_t n_big = static_cast<size_t>(n_entries) / (CANON_WAVE + 1) + 2;
+    CHK(g.biglist.ensure(sizeof(int) * (n_mid + n_big)));
+    int* mid = g.biglist.as<int>();
+    int* big = mid + n_mid;
+    HIPCHK(hipMemsetAsync(mid, 0, sizeof(int), s));
     HIPCHK(hipMemsetAsync(big, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s, ncell, start, order, big);
+    hipLaunchKernelGGL(k_cell_canon, dim3(cdiv(ncell, WG)), dim3(WG), 0, s, ncell, start, order, mid, big);
+    hipLaunchKernelGGL(k_cell_canon_mid, dim3(2048), dim3(WG), 0, s, start, order, mid);
     hipLaunchKernelGGL(k_cell_canon_big, dim3(1024), dim3(WG), 0, s, start, order, big, tmp_val, tmp_rank);
     HIPCHK(hipGetLastError());
     return NBPP_OK;

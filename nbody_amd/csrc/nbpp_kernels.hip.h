@@ -263,21 +263,34 @@ __global__ void k_bin_scatter(int n, const int* __restrict__ cell, const int* __
 
 // The atomic ranks above depend on arrival order; putting each cell's members in
 // ascending original index makes the sorted order a pure function of the input.
-// One thread sorts one cell by insertion, which is right for the few members a cell normally
-// has.  A cell with more than CANON_SMALL members (the core of a collapsed halo holds thousands)
-// is put on a list instead and sorted by a whole workgroup in k_cell_canon_big: by insertion its
-// one thread would need O(members^2) steps while the rest of the GPU waits.
-constexpr int CANON_SMALL = 48;
+// Three sizes of cell.  Up to CANON_TINY members: the one thread that looks at the cell sorts it
+// by insertion.  Up to 64: the cell goes on the `mid` list and one wavefront sorts it by rank in
+// registers (k_cell_canon_mid).  More (the core of a collapsed halo holds thousands): the `big`
+// list and a whole workgroup (k_cell_canon_big).  Insertion by one thread needs O(members^2)
+// dependent steps while the rest of the GPU waits: in a clustered 128^3 set with the limit at 48
+// members this kernel alone took as long as all the other binning passes together.
+constexpr int CANON_TINY = 8;
+constexpr int CANON_WAVE = 64;
 
 __global__ void k_cell_canon(int ncell, const int* __restrict__ start, int* __restrict__ order,
-                             int* __restrict__ big) {   // big[0] = count, big[1..] = cell ids
+                             int* __restrict__ mid, int* __restrict__ big) {   // list[0] = count, list[1..] = cell ids
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncell) return;
-    const int b = start[c], e = start[c + 1];
-    if (e - b > CANON_SMALL) {
-        big[1 + atomicAdd(&big[0], 1)] = c;
-        return;
+    const bool live = c < ncell;
+    const int b = live ? start[c] : 0, e = live ? start[c + 1] : 0;
+    if (e - b > CANON_WAVE) big[1 + atomicAdd(&big[0], 1)] = c;   // few
+    // slots on the mid list: one atomic per wavefront, not per cell (tens of thousands of cells
+    // would otherwise queue up on one counter)
+    const bool to_mid = e - b > CANON_TINY && e - b <= CANON_WAVE;
+    const unsigned long long votes = __ballot(to_mid);
+    if (votes) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll(static_cast<long long>(votes)) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&mid[0], __popcll(votes));
+        base = __shfl(base, leader, 64);
+        if (to_mid) mid[1 + base + __popcll(votes & ((1ull << lane) - 1ull))] = c;
     }
+    if (e - b > CANON_TINY) return;
     for (int p = b + 1; p < e; ++p) {
         const int v = order[p];
         int q = p - 1;
@@ -286,6 +299,24 @@ __global__ void k_cell_canon(int ncell, const int* __restrict__ start, int* __re
             --q;
         }
         order[q + 1] = v;
+    }
+}
+
+// One wavefront per listed cell (9 to 64 members): every lane holds one member, its rank is the
+// number of members with a smaller entry (entries are distinct), counted by passing every member
+// through all lanes.
+__global__ void __launch_bounds__(WG) k_cell_canon_mid(const int* __restrict__ start, int* __restrict__ order,
+                                                       const int* __restrict__ mid) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * WG + threadIdx.x) >> 6, n_waves = (gridDim.x * WG) >> 6;
+    const int n_mid = mid[0];
+    for (int k = wave; k < n_mid; k += n_waves) {
+        const int c = mid[1 + k];
+        const int b = start[c], cnt = start[c + 1] - b;      // wave-uniform
+        const int v = lane < cnt ? order[b + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int u = 0; u < cnt; ++u) rank += __shfl(v, u, 64) < v ? 1 : 0;
+        if (lane < cnt) order[b + rank] = v;                  // every lane read its member before any lane writes
     }
 }
 
