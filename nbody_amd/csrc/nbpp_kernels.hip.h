@@ -320,25 +320,49 @@ __global__ void __launch_bounds__(WG) k_cell_canon_mid(const int* __restrict__ s
     }
 }
 
-// Rank sort of the listed cells, one workgroup per cell at a time: the rank of a member is the
-// number of members with a smaller entry (entries are distinct).  tmp_val / tmp_rank: scratch
-// as long as `order`.
+// The listed cells, one workgroup per cell at a time.  Up to CANON_LDS members: bitonic sort in
+// LDS (a cell of 5000 members takes ~1500 compare-exchanges per thread; counting ranks, the
+// method below, would take 98000 comparisons per thread, half a millisecond for that one cell).
+// Beyond that: rank sort staged through LDS - the rank of a member is the number of members with
+// a smaller entry (entries are distinct); tmp_val / tmp_rank: scratch as long as `order`.
+constexpr int CANON_LDS = 8192;
+
 __global__ void __launch_bounds__(WG) k_cell_canon_big(const int* __restrict__ start, int* __restrict__ order,
                                                        const int* __restrict__ big, int* __restrict__ tmp_val,
                                                        int* __restrict__ tmp_rank) {
-    __shared__ int tile[1024];
+    __shared__ int tile[CANON_LDS];
     const int n_big = big[0];
     for (int k = blockIdx.x; k < n_big; k += gridDim.x) {
         const int c = big[1 + k];
         const int b = start[c], e = start[c + 1];
-        // every thread walks the same number of rounds so that the barriers inside line up
-        const int rounds = (e - b + WG - 1) / WG;
+        const int cnt = e - b;                                  // the same for every thread: barriers line up
+        if (cnt <= CANON_LDS) {
+            int n2 = 128;
+            while (n2 < cnt) n2 <<= 1;
+            __syncthreads();
+            for (int u = threadIdx.x; u < n2; u += WG) tile[u] = u < cnt ? order[b + u] : 0x7fffffff;
+            for (int span = 2; span <= n2; span <<= 1) {
+                for (int j = span >> 1; j > 0; j >>= 1) {
+                    __syncthreads();
+                    for (int t = threadIdx.x; t < (n2 >> 1); t += WG) {
+                        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                        const int a = tile[lo], z = tile[hi];
+                        const bool ascending = (lo & span) == 0;
+                        if ((a > z) == ascending) { tile[lo] = z; tile[hi] = a; }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int u = threadIdx.x; u < cnt; u += WG) order[b + u] = tile[u];
+            continue;
+        }
+        const int rounds = (cnt + WG - 1) / WG;
         for (int r = 0; r < rounds; ++r) {
             const int p = b + r * WG + threadIdx.x;
             const int v = p < e ? order[p] : 0;
             int rank = 0;
-            for (int t0 = b; t0 < e; t0 += 1024) {          // members staged through LDS, 1024 at a time
-                const int len = min(1024, e - t0);
+            for (int t0 = b; t0 < e; t0 += CANON_LDS) {     // members staged through LDS
+                const int len = min(CANON_LDS, e - t0);
                 __syncthreads();
                 for (int u = threadIdx.x; u < len; u += WG) tile[u] = order[t0 + u];
                 __syncthreads();

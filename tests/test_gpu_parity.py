@@ -666,13 +666,15 @@ def test_p3m_extreme_clustering(lib, oracle):
     assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
 
 
+@pytest.mark.parametrize("blobs", [(5000, 2500), (12000, 300)])
 @pytest.mark.parametrize("use_pm", [False, True])
-def test_overfull_cells_are_ordered_deterministically(lib, use_pm):
-    """Cells with thousands of members take the workgroup sort instead of the one-thread
-    insertion sort; the sorted order, and with it every sum of the ordered kernels, must still be
-    a pure function of the input: two evaluations agree bit for bit."""
+def test_overfull_cells_are_ordered_deterministically(lib, oracle, use_pm, blobs):
+    """Cells with thousands of members are sorted by a workgroup (in LDS up to 8192 members, by
+    rank counting beyond) instead of by one thread or one wavefront; the sorted order, and with
+    it every sum of the ordered kernels, must still be a pure function of the input: two
+    evaluations agree bit for bit, and with the oracle to the usual bar."""
     rng = np.random.default_rng(77)
-    pts = np.concatenate([0.21 + 1e-3 * rng.random((5000, 3)), 0.8 + 3e-3 * rng.random((2500, 3)),
+    pts = np.concatenate([0.21 + 1e-3 * rng.random((blobs[0], 3)), 0.8 + 3e-3 * rng.random((blobs[1], 3)),
                           rng.random((9000, 3))])
     pos = [np.ascontiguousarray(pts[:, c]) for c in range(3)]
     m = datasets.masses(pts.shape[0], equal=False)
@@ -685,6 +687,10 @@ def test_overfull_cells_are_ordered_deterministically(lib, use_pm):
         lib.set_option(ffi.OPT_DETERMINISTIC, 0)
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
+    want = oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS if use_pm else O.EXACT)
+    assert normalised_error(a, want) < TOL
+    if use_pm:
+        assert lib.stats()["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
