@@ -36,6 +36,7 @@ struct Ctx {
     int device = -1;
     Buf scratch;     // five conserved meshes: the other side of the sweeps' ping-pong
     Buf blockmax;
+    void* pinned = nullptr;   // 8 KiB of page-locked host memory for the CFL read-back
 };
 Ctx g;
 std::mutex g_mu;
@@ -278,6 +279,7 @@ int nbgas_init(int device) {
     }
     if (device < 0 || device >= count) return fail(NBGAS_ERR_ARG, "device %d out of range [0, %d)", device, count);
     HIPCHK(hipSetDevice(device));
+    HIPCHK(hipHostMalloc(&g.pinned, 8192, hipHostMallocDefault));
     g.device = device;
     g.ready = true;
     return NBGAS_OK;
@@ -290,6 +292,8 @@ void nbgas_shutdown(void) {
     (void)hipDeviceSynchronize();
     g.scratch.release();
     g.blockmax.release();
+    if (g.pinned) (void)hipHostFree(g.pinned);
+    g.pinned = nullptr;
     g.ready = false;
     g.device = -1;
 }
@@ -336,7 +340,7 @@ int nbgas_cfl_timestep_device(const nbgas_params* p, const nbgas_state* s, doubl
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_signal_max, dim3(blocks), dim3(WG), 0, st, total, p->gamma, *s, g.blockmax.as<double>());
     HIPCHK(hipGetLastError());
-    double host[1024];
+    double* host = static_cast<double*>(g.pinned);   // 1024 doubles fit
     HIPCHK(hipMemcpyAsync(host, g.blockmax.p, sizeof(double) * blocks, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     double m = host[0];

@@ -80,6 +80,7 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* pinned = nullptr;           // 8 KiB of page-locked host memory: small read-backs land here without staging
     Buf count, blocksum;              // binning scratch (shared by source and target sorts)
     Sorted src, tgt;
     Buf part[3];                      // per-slice partial sums
@@ -458,14 +459,16 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         HIPCHK(hipMemsetAsync(occ, 0, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_occupancy, dim3(static_cast<int>(std::min<long long>(256, cdiv(ncell, WG)))), dim3(WG), 0, s,
                            static_cast<int>(ncell), count, start, occ);
-        unsigned long long host[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(host, occ, sizeof(host), hipMemcpyDeviceToHost, s));
+        unsigned long long* host = static_cast<unsigned long long*>(g.pinned);
+        HIPCHK(hipMemcpyAsync(host, occ, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         n_entries = static_cast<int>(host[1]);
         if (n_entries > 0) occupancy = static_cast<double>(host[0]) / n_entries;
     } else {
-        HIPCHK(hipMemcpyAsync(&n_entries, start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+        int* host = static_cast<int*>(g.pinned);
+        HIPCHK(hipMemcpyAsync(host, start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        n_entries = host[0];
     }
     if (n_entries < (grid.keep_len == nside ? n_src : n_tgt))
         return fail(NBPP_ERR_HIP, "binning lost particles (%d entries)", n_entries);
@@ -652,6 +655,7 @@ int nbpp_init(int device) {
                     prop.gcnArchName);
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     for (auto& e : g.ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc(&g.pinned, 8192, hipHostMallocDefault));
     g.device = device;
     g.ready = true;
     return NBPP_OK;
@@ -669,6 +673,8 @@ void nbpp_shutdown(void) {
     }
     (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
+    if (g.pinned) (void)hipHostFree(g.pinned);
+    g.pinned = nullptr;
     g.ready = false;
 }
 
@@ -829,11 +835,11 @@ int nbpp_max_accel_sq_device(size_t n, const double* ax, const double* ay, const
     hipLaunchKernelGGL(k_max_accel_sq, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az,
                        g.blockmax.as<double>());
     HIPCHK(hipGetLastError());
-    std::vector<double> h(blocks);
-    HIPCHK(hipMemcpyAsync(h.data(), g.blockmax.p, sizeof(double) * blocks, hipMemcpyDeviceToHost, s));
+    const double* h = static_cast<const double*>(g.pinned);   // 1024 doubles fit
+    HIPCHK(hipMemcpyAsync(g.pinned, g.blockmax.p, sizeof(double) * blocks, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     double m = 1e-9;
-    for (double v : h) m = (v > m) ? v : m;  // strict '>' as src/integrator.cpp:209
+    for (int b = 0; b < blocks; ++b) m = (h[b] > m) ? h[b] : m;  // strict '>' as src/integrator.cpp:209
     *out_host = m;
     return NBPP_OK;
 }
