@@ -109,13 +109,41 @@ __global__ void __launch_bounds__(WG) k_cic_deposit(size_t n, const double* __re
                                                     const double* __restrict__ m, double cell,
                                                     double cell_volume, int N, double* __restrict__ rho) {
     const size_t i = xcd_piece() * WG + threadIdx.x;
-    if (i >= n) return;
-    const Cloud c = cloud_of(x[i], y[i], z[i], cell, N);
+    const bool live = i < n;
+    const size_t at = live ? i : n - 1;
+    const Cloud c = cloud_of(x[at], y[at], z[at], cell, N);
     double w[8];
     cloud_weights(c, w);
-    const double mi = m[i];
+    const double mi = live ? m[at] : 0.0;
+    double term[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) unsafeAtomicAdd(&rho[corner(c, q, N)], (mi * w[q]) / cell_volume);
+    for (int q = 0; q < 8; ++q) term[q] = (mi * w[q]) / cell_volume;
+    // Neighbours in the particle order that sit in the same cell add to the same eight mesh cells:
+    // once particles have clustered, most of a wavefront's atomics pile onto a few addresses.  Runs
+    // of consecutive lanes with the same cell are summed inside the wavefront first (segmented
+    // suffix sum) and the first lane of each run issues the atomics.  A wavefront without such a run
+    // (the initial lattice) skips all of it.
+    const int lane = threadIdx.x & 63;
+    const long long key = (static_cast<long long>(c.i0[0]) * N + c.i0[1]) * N + c.i0[2];
+    const long long prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || prev != key || !live;
+    const unsigned long long heads = __ballot(head);
+    if (heads != ~0ull) {
+        const int run = __popcll(heads & ((2ull << lane) - 1ull));   // 1-based index of this lane's run
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int other_run = __shfl_down(run, d, 64);
+            const bool same = lane + d < 64 && other_run == run;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double other = __shfl_down(term[q], d, 64);
+                term[q] += same ? other : 0.0;
+            }
+        }
+    }
+    if (!live || !head) return;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) unsafeAtomicAdd(&rho[corner(c, q, N)], term[q]);
 }
 
 // phi_k = rho_k * (-4 pi G / k^2), phi_0 = 0                      src/integrator.cpp:78-103
