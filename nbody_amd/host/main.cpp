@@ -49,11 +49,16 @@ int main(int argc, char** argv) {
     std::printf("N(P,G): (%d^3,%d^3) G: %g fixed_dt: %g\n", config.N_PER_SIDE, config.MESH_SIZE, config.G, config.FIXED_DT);
 
     const std::string run_dir = "outputs/run_" + timestamp();                        // :53-61
-    std::filesystem::create_directories(run_dir);
-    // the reference copies ./simulation.ini whatever file it loaded; the file that was loaded is
-    // the one worth keeping
-    std::filesystem::copy_file(config_filename, run_dir + "/simulation.ini",
-                               std::filesystem::copy_options::overwrite_existing);
+    try {
+        std::filesystem::create_directories(run_dir);
+        // the reference copies ./simulation.ini whatever file it loaded; the file that was loaded
+        // is the one worth keeping
+        std::filesystem::copy_file(config_filename, run_dir + "/simulation.ini",
+                                   std::filesystem::copy_options::overwrite_existing);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Error preparing %s: %s\n", run_dir.c_str(), e.what());
+        return 1;
+    }
 
     try {
         if (nbpp_init(0) != NBPP_OK) throw std::runtime_error(nbpp_last_error());
