@@ -505,8 +505,12 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         CHK(g.src.rank.ensure(sizeof(int) * (ncol + 1)));
         int* col_count = g.src.cell.as<int>();
         int* col_start = g.src.rank.as<int>();
-        hipLaunchKernelGGL(k_column_counts, dim3(cdiv(ncol + 1, WG)), dim3(WG), 0, s, grid, start, col_count);
-        CHK(exclusive_scan(ncol + 1, col_count, col_start, s));
+        if (ncol <= 16384) {
+            hipLaunchKernelGGL(k_column_starts_small, dim3(1), dim3(1024), 0, s, grid, start, col_start);
+        } else {
+            hipLaunchKernelGGL(k_column_counts, dim3(cdiv(ncol + 1, WG)), dim3(WG), 0, s, grid, start, col_count);
+            CHK(exclusive_scan(ncol + 1, col_count, col_start, s));
+        }
         hipLaunchKernelGGL(k_column_targets, dim3(std::min(ncol, 65536)), dim3(WG), 0, s, grid, start, col_start,
                            tlist);
     } else {
@@ -523,8 +527,10 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     }
     HIPCHK(hipGetLastError());
     CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
-    if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[1], s));
+    if (g.opt_timing) {   // the accepted-pair counter is only kept when timing
+        HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
+        HIPCHK(hipEventRecord(g.ev[1], s));
+    }
 
     // 4. pairs
     P3MArgs a{};

@@ -917,6 +917,42 @@ __global__ void k_column_counts(GhostGrid g, const int* __restrict__ cell_start,
     count[col] = c;
 }
 
+// The two steps above (counts, exclusive scan into col_start[0 .. np^2]) in one launch of one
+// workgroup of 1024 threads, for grids of up to a few thousand columns, where four launches cost
+// more than the work.
+__global__ void __launch_bounds__(1024) k_column_starts_small(GhostGrid g, const int* __restrict__ cell_start,
+                                                              int* __restrict__ col_start) {
+    __shared__ int wave_total[16];
+    const int ncol = g.np * g.np;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base <= ncol; base += 1024) {      // entry ncol is the total
+        const int col = base + threadIdx.x;
+        int c = 0;
+        if (col < ncol) {
+            const int X = col / g.np, Y = col - X * g.np;
+            if (X >= g.R && X < g.np - g.R && Y >= g.R && Y < g.np - g.R)
+                c = cell_start[col * g.np + g.np - g.R] - cell_start[col * g.np + g.R];
+        }
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_total[wave] = inc;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            before += w < wave ? wave_total[w] : 0;
+            total += wave_total[w];
+        }
+        if (col <= ncol) col_start[col] = carry + before + inc - c;
+        carry += total;
+        __syncthreads();
+    }
+}
+
 // col_start = exclusive scan of the counts above: the list positions of a column's real entries
 __global__ void __launch_bounds__(WG) k_column_targets(GhostGrid g, const int* __restrict__ cell_start,
                                                        const int* __restrict__ col_start,
