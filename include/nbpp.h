@@ -151,6 +151,28 @@ int nbpp_accumulate_device(const nbpp_params* p, size_t n_src,
                            double* ax, double* ay, double* az, void* stream);
 
 /*
+ * nbpp_accumulate_device over all targets (tgt_begin = 0, n_tgt = n) for callers that cannot
+ * allocate device memory: code under HIP graph capture set-up, tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference.  The call makes no hipMalloc / hipFree and
+ * calls no allocating library routine; the sorted copies, cell lists, queues and partial sums that
+ * nbpp_accumulate_device keeps in buffers it allocates live here in one fixed array of
+ * NBPP_NOALLOC_SCRATCH_BYTES inside the library's code object (every GPU the library runs on
+ * holds that much from load time until the process ends).  Same kernels, same results, same
+ * stream semantics and options as nbpp_accumulate_device.
+ * Limits: n <= NBPP_NOALLOC_MAX_N, else NBPP_ERR_RANGE; parameters whose search grid does not
+ * fit the array (a cutoff radius far below the particle spacing) also give NBPP_ERR_RANGE with
+ * the sizes in the message, and nothing has been added to ax, ay, az then.
+ * All calls on one GPU share the array: two such calls must not overlap in time (issue them on
+ * one stream, or order the streams), or they overwrite each other's work.
+ */
+#define NBPP_NOALLOC_MAX_N 262144                      /* 64^3 particles */
+#define NBPP_NOALLOC_SCRATCH_BYTES (48u * 1024u * 1024u)
+int nbpp_accumulate_device_noalloc(const nbpp_params* p, size_t n,
+                                   const double* x, const double* y, const double* z,
+                                   const double* m, double* ax, double* ay, double* az,
+                                   void* stream);
+
+/*
  * One share of a direct-summation (use_pm == 0) evaluation, for multi-GPU runs that use every
  * pair once: the unordered pairs {i, j} of the n particles are divided into n_parts equal
  * shares; this call evaluates share `part` and adds BOTH a_i and a_j of each of its pairs into

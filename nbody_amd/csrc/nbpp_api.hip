@@ -17,6 +17,13 @@
 
 using namespace nbpp;
 
+// Workspace of nbpp_accumulate_device_noalloc, the entry point that must not allocate: one array
+// in the code object, so every GPU that loads the library holds its own copy from load time until
+// the process ends.  In host code this name is only a handle for hipGetSymbolAddress, never an
+// address: nbpp_init asks the runtime where the current device's copy lives and everything else
+// (kernel arguments, memsets, copies) goes through that pointer (Ctx::fixed).
+static __device__ __align__(256) unsigned char scratch[NBPP_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -44,12 +51,32 @@ int fail(int code, const char* fmt, ...) {
         if (rc_ != NBPP_OK) return rc_; \
     } while (0)
 
-// Device buffer that only grows.
+// Fixed device memory that buffers are carved from, front to back, instead of being allocated.
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+};
+
+// Device buffer that only grows.  With an arena it takes its memory from there (a piece it has
+// outgrown is not reused before the arena is reset) and never calls the allocator.
 struct Buf {
     void* p = nullptr;
     size_t cap = 0;
+    Arena* arena = nullptr;
     int ensure(size_t bytes) {
         if (bytes <= cap) return NBPP_OK;
+        if (arena) {
+            const size_t off = (arena->used + 255) & ~static_cast<size_t>(255);
+            if (off > arena->size || bytes > arena->size - off)
+                return fail(NBPP_ERR_RANGE,
+                            "this call needs more than the %zu bytes of the library's fixed workspace "
+                            "(a %zu-byte buffer at offset %zu); use nbpp_accumulate_device",
+                            arena->size, bytes, off);
+            p = arena->base + off;
+            cap = bytes;
+            arena->used = off + bytes;
+            return NBPP_OK;
+        }
         if (p) HIPCHK(hipFree(p));
         p = nullptr;
         cap = 0;
@@ -59,7 +86,7 @@ struct Buf {
         return NBPP_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !arena) (void)hipFree(p);
         p = nullptr;
         cap = 0;
     }
@@ -70,17 +97,16 @@ struct Buf {
 struct Sorted {
     Buf cell, rank, order, start, x, y, z, gm, box;
     int n = 0, npad = 0;
+    template <class F> void each(F f) {
+        for (Buf* b : {&cell, &rank, &order, &start, &x, &y, &z, &gm, &box}) f(*b);
+    }
     void release() {
-        for (Buf* b : {&cell, &rank, &order, &start, &x, &y, &z, &gm, &box}) b->release();
+        each([](Buf& b) { b.release(); });
     }
 };
 
-struct Ctx {
-    bool ready = false;
-    int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    void* pinned = nullptr;           // 8 KiB of page-locked host memory: small read-backs land here without staging
+// Every device buffer a compute call works in.
+struct Work {
     Buf count, blocksum;              // binning scratch (shared by source and target sorts)
     Sorted src, tgt;
     Buf part[3];                      // per-slice partial sums
@@ -89,17 +115,29 @@ struct Ctx {
     Buf blockmax, counter, massinfo;
     Buf biglist;                      // cells too full for the one-thread sort: two lists of count, ids
     Buf ghostcode;                    // P3M: image code of every sorted entry
-    int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0;
-    nbpp_stats stats{};
-    void release() {
+    template <class F> void each(F f) {
         for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
                        &host_in[1], &host_in[2], &host_in[3], &host_acc[0], &host_acc[1],
                        &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter, &massinfo, &biglist, &ghostcode})
-            b->release();
-        src.release();
-        tgt.release();
+            f(*b);
+        src.each(f);
+        tgt.each(f);
     }
+    void release() {
+        each([](Buf& b) { b.release(); });
+    }
+};
+
+struct Ctx : Work {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* pinned = nullptr;           // 8 KiB of page-locked host memory: small read-backs land here without staging
+    Arena fixed;                      // the device's copy of the fixed workspace (nbpp_accumulate_device_noalloc)
+    int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
+            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0;
+    nbpp_stats stats{};
 };
 
 Ctx g;
@@ -662,6 +700,12 @@ int nbpp_init(int device) {
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     for (auto& e : g.ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipHostMalloc(&g.pinned, 8192, hipHostMallocDefault));
+    // this device's copy of the fixed workspace (the device was made current above)
+    void* fixed = nullptr;
+    HIPCHK(hipGetSymbolAddress(&fixed, HIP_SYMBOL(scratch)));
+    g.fixed.base = static_cast<char*>(fixed);
+    g.fixed.size = NBPP_NOALLOC_SCRATCH_BYTES;
+    g.fixed.used = 0;
     g.device = device;
     g.ready = true;
     return NBPP_OK;
@@ -673,6 +717,7 @@ void nbpp_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     g.release();
+    g.fixed = Arena{};
     for (auto& e : g.ev) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
@@ -718,6 +763,35 @@ int nbpp_accumulate_device(const nbpp_params* p, size_t n_src, const double* x, 
     HIPCHK(hipSetDevice(g.device));
     hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
     return compute_on_device(p, n_src, x, y, z, m, tgt_begin, n_tgt, ax, ay, az, s);
+}
+
+int nbpp_accumulate_device_noalloc(const nbpp_params* p, size_t n, const double* x, const double* y,
+                                   const double* z, const double* m, double* ax, double* ay,
+                                   double* az, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    CHK(check_params(p));
+    if (n > NBPP_NOALLOC_MAX_N)
+        return fail(NBPP_ERR_RANGE,
+                    "nbpp_accumulate_device_noalloc takes at most %d particles (got %zu); "
+                    "use nbpp_accumulate_device",
+                    NBPP_NOALLOC_MAX_N, n);
+    if (n == 0) return NBPP_OK;
+    if (!x || !y || !z || !m || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    std::lock_guard<std::mutex> lock(g_mu);
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
+    // For the length of this call the working buffers are empty ones that take their memory from
+    // the fixed workspace, front to back; the allocated buffers of the other entry points are set
+    // aside and come back untouched.  Every kernel that expects zeros (histograms, counters,
+    // list heads) clears them itself, as it must for reused allocated buffers too, so what the
+    // last call left in the workspace does not matter.
+    Work saved;
+    std::swap(static_cast<Work&>(g), saved);
+    g.fixed.used = 0;
+    static_cast<Work&>(g).each([](Buf& b) { b.arena = &g.fixed; });
+    const int rc = compute_on_device(p, n, x, y, z, m, 0, n, ax, ay, az, s);
+    static_cast<Work&>(g) = saved;
+    return rc;
 }
 
 int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n, const double* x, const double* y,

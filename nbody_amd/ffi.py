@@ -12,12 +12,15 @@ LIB_PATH = os.environ.get("NBPP_LIB") or os.path.join(HERE, "lib", "libnbpp.so")
 
 KERNEL_NONE, KERNEL_DIRECT, KERNEL_DIRECT_WRAP, KERNEL_P3M_CELLS, KERNEL_P3M_ALLPAIRS, \
     KERNEL_DIRECT_SYMMETRIC = range(6)
+NOALLOC_MAX_N = 262144                 # NBPP_NOALLOC_MAX_N
+NOALLOC_SCRATCH_BYTES = 48 * 1024 * 1024  # NBPP_NOALLOC_SCRATCH_BYTES
 OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SEARCH_RADIUS, \
     OPT_NO_EQUAL_MASS_PATH, OPT_DETERMINISTIC, OPT_P3M_LANES_PER_TARGET = 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = (
     "nbpp_init", "nbpp_shutdown", "nbpp_last_error", "nbpp_set_option", "nbpp_get_stats",
-    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device", "nbpp_add_device",
+    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_accumulate_device_noalloc",
+    "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device", "nbpp_add_device",
     "nbpp_max_accel_sq_device",
 )
 
@@ -90,6 +93,8 @@ class Library:
         L.nbpp_accumulate.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7
         L.nbpp_accumulate_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 4 + [
             C.c_size_t, C.c_size_t] + [_DP] * 3 + [C.c_void_p]
+        L.nbpp_accumulate_device_noalloc.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7 + [
+            C.c_void_p]
         L.nbpp_accumulate_pairs_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 4 + [
             C.c_int, C.c_int] + [_DP] * 3 + [C.c_void_p]
         L.nbpp_kick_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 3 + [C.c_void_p]
@@ -138,6 +143,16 @@ class Library:
         self._check(self.lib.nbpp_accumulate_device(
             C.byref(p), n_src, _dev(x), _dev(y), _dev(z), _dev(m), tgt_begin, n_tgt,
             _dev(ax), _dev(ay), _dev(az), C.c_void_p(stream or 0)))
+
+    def accumulate_device_noalloc(self, p, x, y, z, m, ax, ay, az, stream=None):
+        """All targets, working memory from the library's fixed array only
+        (nbpp_accumulate_device_noalloc)."""
+        n = x.numel()
+        if min(ax.numel(), ay.numel(), az.numel()) < n:
+            raise ValueError("acceleration arrays must hold all n particles")
+        self._check(self.lib.nbpp_accumulate_device_noalloc(
+            C.byref(p), n, _dev(x), _dev(y), _dev(z), _dev(m), _dev(ax), _dev(ay), _dev(az),
+            C.c_void_p(stream or 0)))
 
     def accumulate_pairs_device(self, p, x, y, z, m, ax, ay, az, part=0, n_parts=1, stream=None):
         """Share `part` of `n_parts` of all unordered pairs into full-length ax/ay/az
