@@ -31,7 +31,9 @@ def cpu_baseline(p, pos, m, mode, budget_s=15.0):
     from oracle.oracle import Oracle, EXACT_CELLS, EXACT
     orc = Oracle(fast=True)
     n = m.size
-    cores = min(orc.max_threads(), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    # every thread OpenMP grants this process: omp_get_max_threads(), i.e. OMP_NUM_THREADS where
+    # the box sets it (its CPU share for one GPU), else every core the process may run on
+    cores = orc.max_threads()
     if mode == "direct":
         n_tgt = 64 * cores
         while True:
@@ -54,8 +56,116 @@ def cpu_baseline(p, pos, m, mode, budget_s=15.0):
             n_tgt = min(n, int(n_tgt * max(2.0, 0.6 * budget_s / max(dt, 1e-3))))
         pairs = orc.count_within_cutoff(p, *pos, tgt_begin=0, n_tgt=n_tgt, nthreads=cores)
         sample = f"{n_tgt} targets, cell search over the reference's mesh cells, {dt:.2f} s"
-    return {"value": pairs / dt / 1e9, "unit": "Ginter/s", "cores": cores, "kind": "port",
-            "sample": sample, "build": "fast" if orc.fast else "strict"}
+    out = {"value": pairs / dt / 1e9, "unit": "Ginter/s", "cores": cores, "kind": "port",
+           "sample": sample, "build": "fast" if orc.fast else "strict",
+           "host_cores_visible": os.cpu_count(), "host_cores_usable": len(os.sched_getaffinity(0)),
+           "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS")}
+    if mode == "direct":
+        out["config1_kdk_step_32cubed"] = cpu_config1_kdk_step(orc, cores)
+    return out
+
+
+def cpu_config1_kdk_step(orc, cores):
+    """BASELINE config 1 as written: PP direct summation, 32^3 particles, one whole KDK step
+    (kick, drift, full force evaluation, kick: src/integrator.cpp:215-275 without mesh and gas) of
+    the CPU port on the host cores, every target against every source."""
+    from nbody_amd import Config
+    import datasets
+    n_side = 32
+    n = n_side ** 3
+    config = Config(MESH_SIZE=31, N_PER_SIDE=n_side, USE_PM=False)   # odd mesh: the exact regime
+    p = config.pp_params()
+    pos = [np.ascontiguousarray(c).copy() for c in datasets.zeldovich(n_side)]   # seed 42, as shipped
+    m = np.full(n, config.DM_PARTICLE_MASS)
+    vel = [np.zeros(n) for _ in range(3)]
+    acc = list(orc.accumulate(p, *pos, m, nthreads=cores))            # initial accelerations
+    dt = config.FIXED_DT
+    t0 = time.perf_counter()
+    orc.kick(vel, acc, dt / 2.0, 1.0, 0.0)
+    orc.drift(pos, vel, dt, config.DOMAIN_SIZE)
+    t1 = time.perf_counter()
+    acc = list(orc.accumulate(p, *pos, m, nthreads=cores))
+    t2 = time.perf_counter()
+    orc.kick(vel, acc, dt / 2.0, 1.0, 0.0)
+    t3 = time.perf_counter()
+    pairs = n * (n - 1)
+    return {"seconds": t3 - t0, "force_seconds": t2 - t1, "Ginter_per_s": pairs / (t2 - t1) / 1e9,
+            "pairs": pairs, "cores": cores}
+
+
+def extra_p3m256(lib, ffi, torch, dev, stream, steps=6, warmup=2):
+    """BASELINE config 3 under the same clock: P3M short range (GPU cell list) at 256^3."""
+    from nbody_amd import Config
+    import datasets
+    n_side = 256
+    n = n_side ** 3
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    p = config.pp_params()
+    pos = datasets.jittered_lattice(n_side)
+    x, y, z = [torch.from_numpy(c).to(dev) for c in pos]
+    del pos
+    mass = torch.full((n,), config.DM_PARTICLE_MASS, dtype=torch.float64, device=dev)
+    acc = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(3)]
+    for k in (ffi.OPT_TARGETS_PER_LANE, ffi.OPT_FORCE_KERNEL, ffi.OPT_P3M_SEARCH_RADIUS,
+              ffi.OPT_P3M_LANES_PER_TARGET, ffi.OPT_DETERMINISTIC):
+        lib.set_option(k, 0)
+    for _ in range(warmup):
+        lib.accumulate_device(p, x, y, z, mass, *acc, stream=stream)
+    torch.cuda.synchronize()
+    kernel_ms, prep_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lib.accumulate_device(p, x, y, z, mass, *acc, stream=stream)
+        st = lib.stats()
+        kernel_ms.append(st["pair_kernel_ms"])
+        prep_ms.append(st["prepare_ms"])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    accepted = float(st["pairs_accepted"])
+    k_ms = float(np.mean(kernel_ms))
+    achieved = accepted * FLOPS_PER_PAIR_P3M / (k_ms * 1e-3) / 1e12
+    return {"workload": "P3M short range, 256^3 particles, mesh 256, cutoff 2.5 cells (BASELINE config 3)",
+            "value": accepted * steps / elapsed / 1e9, "unit": "G accepted pairs/s",
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+            "pairs_accepted": accepted, "kernel": "k_p3m_cells", "kernel_ms": k_ms,
+            "prepare_ms": float(np.mean(prep_ms)),
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                         "flops_per_accepted_pair": FLOPS_PER_PAIR_P3M}}
+
+
+def extra_step128(cycles=100):
+    """BASELINE config 5 under the same clock: the product's own C++ engine (a child process) runs
+    tools/configs/p3m_hydro_128.ini for `cycles` KDK cycles, state resident in HBM.  Two runs:
+    one untimed inside (wall ms per cycle, force phases overlapped as in production), one with
+    every cycle's phases timed by HIP events (the reference's PM / PP / Hydro timer split,
+    src/integrator.cpp:228,238,255)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "nbody_amd", "host", "nbody_host_tests")
+    ini = os.path.join(ROOT, "tools", "configs", "p3m_hydro_128.ini")
+    if not os.path.exists(exe):
+        return {"error": f"{exe} not built"}
+    pat = re.compile(r"timing: (\d+) cycles, (\S+) ms/cycle wall; PP (\S+), mesh (\S+), hydro sweeps (\S+) ms/cycle "
+                     r"\(device, (\d+) timed cycles\)")
+    out = {"workload": "P3M + HLL hydro, 128^3 particles + 128^3 gas mesh, 100 KDK cycles (BASELINE config 5)",
+           "cycles": cycles}
+    for label, timing_every in (("wall", "0"), ("split", "1")):
+        r = subprocess.run([exe, "run", ini, str(cycles), "", "", timing_every], capture_output=True,
+                           text=True, timeout=300)
+        t = pat.search(r.stdout)
+        if r.returncode != 0 or not t:
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        if label == "wall":
+            out["ms_per_cycle"] = float(t[2])
+        else:
+            out["ms_per_cycle_with_phase_timers"] = float(t[2])
+            out["device_ms_per_cycle"] = {"pp_short_range": float(t[3]), "mesh_force": float(t[4]),
+                                          "hydro_sweeps": float(t[5]), "timed_cycles": int(t[6])}
+    gas = re.findall(r"gas mass (\S+)", r.stdout)
+    if len(gas) == 2:
+        out["gas_mass_drift"] = abs(float(gas[1]) - float(gas[0])) / float(gas[0])
+    return out
 
 
 def main():
@@ -70,6 +180,9 @@ def main():
                     help="particles per side; default 128 (direct) or 256 (p3m), the headline sizes")
     ap.add_argument("--mode", choices=["direct", "p3m"], default="direct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the P3M 256^3 and 128^3 whole-step figures that ride along in the "
+                         "default one-GPU line (`extra`)")
     ap.add_argument("--per-lane", type=int, default=0)
     ap.add_argument("--force-kernel", type=int, default=0)
     ap.add_argument("--p3m-radius", type=int, default=0)
@@ -255,6 +368,24 @@ def main():
             line["config"]["mesh_force_ms"] = float(np.mean(mesh_ms[args.warmup:]))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(p, pos, m, args.mode)
+        default_run = (world == 1 and args.mode == "direct" and n_side == 128 and not args.with_mesh
+                       and not args.no_extras)
+        if default_run:
+            # the other single-GPU configurations of the baseline, measured by the same process
+            # under the same clock (not part of `value`)
+            del parts, acc, mass
+            torch.cuda.empty_cache()
+            extra = {}
+            try:
+                extra["p3m256"] = extra_p3m256(lib, ffi, torch, dev, stream)
+            except Exception as e:   # the headline line must still be printed
+                extra["p3m256"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            try:
+                extra["step128"] = extra_step128()
+            except Exception as e:
+                extra["step128"] = {"error": repr(e)}
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

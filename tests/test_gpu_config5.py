@@ -1,0 +1,106 @@
+"""The full step at its stated size: P3M gravity + HLL gas, 128^3 particles on a 128^3 mesh,
+100 KDK cycles with everything resident in HBM (tools/configs/p3m_hydro_128.ini), through the
+C++ engine.  Checked on the run's own first and last snapshots:
+
+* gas mass conserved to 1e-12 (the finite-volume update moves mass between cells only,
+  src/gas.cpp hydro_step);
+* no net momentum appears: |sum p| / sum |p| over particles and gas stays at rounding level
+  (pairwise antisymmetric short-range force, CIC deposit and interpolation with the same weights);
+* the accelerations the engine holds after the last cycle equal, for sampled particles, the
+  CPU oracle's force on the downloaded state (numpy mesh force from particles + gas density,
+  plus the short-range sum), max_i,c |a - a_ref|_c / ||a_ref,i||_2 <= 1e-10;
+* the timer split the reference prints (Step / PM / PP / Hydro, src/integrator.cpp:228,238,255)
+  is reported and consistent.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, normalised_error
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "nbody_amd", "host", "nbody_host_tests")
+INI = os.path.join(ROOT, "tools", "configs", "p3m_hydro_128.ini")
+
+
+def test_config5_128cubed_p3m_hydro_100_cycles(tmp_path, oracle):
+    from nbody_amd import Config, snapshot
+    from oracle import pm_mesh
+    from oracle.oracle import EXACT_CELLS
+    if not snapshot.hdf5_available():
+        pytest.skip("no HDF5 library on this machine")
+    # the shipped configuration, with snapshots at the start and the end only
+    ini = tmp_path / "run.ini"
+    ini.write_text(open(INI).read() + "save_hdf5_every_delta_a = 10.0\n")
+    out = tmp_path / "snapshots"
+    out.mkdir()
+    r = subprocess.run([BIN, "run", str(ini), "100", str(out), "", "10"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = r.stdout
+    gas_mass = [float(v) for v in re.findall(r"gas mass (\S+)", text)]
+    assert len(gas_mass) == 2
+    assert abs(gas_mass[1] - gas_mass[0]) <= 1e-12 * gas_mass[0]
+    t = re.search(r"timing: (\d+) cycles, (\S+) ms/cycle wall; PP (\S+), mesh (\S+), hydro sweeps (\S+) ms/cycle "
+                  r"\(device, (\d+) timed cycles\)", text)
+    assert t, text
+    cycles, wall, pp, mesh, hydro, timed = int(t[1]), float(t[2]), float(t[3]), float(t[4]), float(t[5]), int(t[6])
+    assert cycles == 100 and timed == 10
+    assert 0.0 < pp and 0.0 < mesh and 0.0 < hydro
+    assert pp + mesh + hydro < 1.5 * wall          # the split accounts for device time inside the wall time
+    assert wall < 50.0                             # ms per cycle: an order of magnitude above what was measured
+
+    first = snapshot.read_snapshot(out / "snapshot_0000.hdf5")
+    last = snapshot.read_snapshot(out / "snapshot_0001.hdf5")
+    assert last["attrs"]["scale_factor"] > 0.2 > first["attrs"]["scale_factor"]
+    config = Config(MESH_SIZE=128, N_PER_SIDE=128, OMEGA_BARYON=0.048, USE_PM=True)
+    M, L = 128, config.DOMAIN_SIZE
+    n = M ** 3
+    V = (L / M) ** 3
+    for s in (first, last):
+        assert s["particles"]["mass"].size == n and s["gas"]["density"].size == n
+    assert float(np.sum(last["gas"]["density"])) * V == pytest.approx(float(np.sum(first["gas"]["density"])) * V,
+                                                                       rel=1e-12)
+    # momentum.  The dark matter starts with none (tests/test_ics.cpp:79-97 asks |p_x| < 1e-10); the
+    # gas starts with a small net momentum (density-weighted velocities; the same test allows 1e-3).
+    # Forces add nothing to the total (pairwise antisymmetric short-range force; deposit and
+    # interpolation with the same weights; central differences of a symmetric Green's function;
+    # conservative fluxes), so all that happens to the net momentum is the Hubble drag of the
+    # kicks, one common factor D for the three components: P_last = D P_first, 0 < D < 1.
+    def net_momentum(s):
+        P = []
+        for c in "xyz":
+            dm = float(np.sum(s["particles"]["mass"] * s["particles"][f"velocity_{c}"]))
+            gas = float(np.sum(s["gas"][f"momentum_{c}"])) * V
+            P.append((dm, gas))
+        return np.array(P)
+    P0, P1 = net_momentum(first), net_momentum(last)
+    assert np.all(np.abs(P0[:, 0]) < 1e-10) and np.all(np.abs(P0[:, 1]) < 1e-3)
+    t0, t1 = P0.sum(axis=1), P1.sum(axis=1)
+    D = float(t1 @ t0) / float(t0 @ t0)
+    assert 0.0 < D < 1.0
+    drift = float(np.linalg.norm(t1 - D * t0)) / float(np.linalg.norm(t1))
+    print(f"net momentum {t0} -> {t1}: common drag factor {D:.6f}, residual {drift:.2e}")
+    assert drift < 1e-6
+
+    # the force on the final state, sampled targets
+    p = last["particles"]
+    pos = [np.ascontiguousarray(p[f"position_{c}"]) for c in "xyz"]
+    pos = [np.where(c >= L, c - L, c) for c in pos]          # the drift's fold can return exactly L
+    mass = np.ascontiguousarray(p["mass"])
+    rho, idx, weights = pm_mesh.cic_deposit(pos, mass, M, L)
+    total = rho + last["gas"]["density"].reshape(M, M, M)    # src/integrator.cpp:57-59
+    grids = pm_mesh.poisson_accelerations(total, L, config.G)
+    n_tgt = 4096
+    sub_idx = [i[:n_tgt] for i in idx]
+    sub_w = [(corner, w[:n_tgt]) for corner, w in weights]
+    ref = [np.ascontiguousarray(a) for a in pm_mesh.cic_interpolate(grids, sub_idx, sub_w)]
+    oracle.accumulate(config.pp_params(), *pos, mass, acc=ref, tgt_begin=0, n_tgt=n_tgt, traversal=EXACT_CELLS)
+    got = [p[f"acceleration_{c}"][:n_tgt] for c in "xyz"]
+    err = normalised_error(got, ref)
+    print(f"config 5: {wall:.3f} ms/cycle wall (PP {pp:.3f}, mesh {mesh:.3f}, hydro {hydro:.3f}); "
+          f"final force vs oracle {err:.2e}")
+    assert err < 1e-10
