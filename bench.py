@@ -190,6 +190,13 @@ def main():
     ap.add_argument("--with-mesh", action="store_true",
                     help="p3m mode, one GPU: a step is the whole force phase, mesh force "
                          "(libnbpm) then short range accumulated onto it")
+    ap.add_argument("--comm", choices=["native", "torch"], default="native",
+                    help="several GPUs: 'native' = libnbmg (the library owns the RCCL communicator, "
+                         "ncclAllGather / ncclReduceScatter below the C ABI), 'torch' = the same "
+                         "collectives issued through torch.distributed")
+    ap.add_argument("--native-one-rank", action="store_true",
+                    help="one GPU: go through libnbmg with a communicator of one rank (exercises the "
+                         "multi-GPU code path on a single-GPU box)")
     ap.add_argument("--ordered", action="store_true",
                     help="bitwise-reproducible ordered-pair kernel (NBPP_OPT_DETERMINISTIC)")
     args = ap.parse_args()
@@ -253,6 +260,42 @@ def main():
         lib.accumulate_pairs_device(p, x, y, z, mm, fx, fy, fz, part=part, n_parts=n_parts,
                                     stream=stream)
 
+    # several GPUs, native path: libnbmg owns an RCCL communicator of its own; torch.distributed
+    # only carries the communicator id to the ranks and the barrier / max-over-ranks of the timing
+    mg = None
+    comm_note = None
+    if world == 1 and args.native_one_rank:
+        mg = nbody_amd.load_multi_gpu()
+        mg.init(0, 1, None, local_rank)
+        mg.set_option(ffi.MG_OPT_TIMING, 1)
+        mg.set_option(ffi.MG_OPT_PAIR_SHARES, -1 if args.ordered else 1)
+    if world > 1 and args.comm == "native" and not rehearsal:
+        try:
+            mg = nbody_amd.load_multi_gpu()
+            ident = torch.zeros(ffi.MG_UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                ident.copy_(torch.frombuffer(bytearray(mg.unique_id()), dtype=torch.uint8))
+            dist.broadcast(ident, src=0)
+            mg.init(rank, world, bytes(ident.cpu().numpy().tobytes()), local_rank)
+            mg.set_option(ffi.MG_OPT_TIMING, 1)
+            mg.set_option(ffi.MG_OPT_PAIR_SHARES, -1 if args.ordered else 0)
+            ok = 1
+        except Exception as e:   # every rank must take the same path: agree below
+            comm_note = f"native multi-GPU layer failed to start ({e!r}); torch.distributed collectives used"
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            mg = None
+            comm_note = comm_note or "native multi-GPU layer failed on another rank; torch.distributed collectives used"
+    if mg is not None:
+        nb_begin, nb_count = mg.partition(n, rank, world)
+        nb_own = [torch.from_numpy(c[nb_begin:nb_begin + nb_count].copy()).to(dev) for c in pos]
+        nb_mass = torch.zeros(mg.padded_length(n, world), dtype=torch.float64, device=dev)
+        nb_mass[:n] = config.DM_PARTICLE_MASS
+        nb_acc = [torch.zeros(max(nb_count, 1), dtype=torch.float64, device=dev) for _ in range(3)]
+    comm_ms = []
+
     from nbody_amd.distributed import force_evaluation_pairs
     # direct summation on several GPUs: every unordered pair once, shared out over the ranks,
     # accelerations combined by reduce-scatter; one GPU (or P3M): the ordinary entry point,
@@ -270,6 +313,15 @@ def main():
     mesh_ms = []
 
     def step():
+        if mg is not None:
+            # the multi-GPU compute_pp_forces of libnbmg: all-gather of positions, this rank's share
+            # of the pairs, reduce-scatter (direct) or this rank's targets (P3M / --ordered)
+            for a in nb_acc:
+                a.zero_()
+            mg.accumulate_device(p, n, *nb_own, nb_mass, *nb_acc, stream=stream)
+            ms = mg.stats()
+            comm_ms.append((ms["allgather_ms"], ms["reduce_ms"], ms["compute_ms"]))
+            return lib.stats()
         if mesh is not None:   # src/integrator.cpp:239-258: the mesh force overwrites, PP adds
             x, y, z = parts.gather_positions()
             mesh.accelerations_device(mesh_params, x, y, z, mass, *acc, stream=stream)
@@ -290,6 +342,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    del comm_ms[:]
     fence()
     t0 = time.perf_counter()
     kernel_ms, prep_ms, accepted = [], [], 0
@@ -326,7 +379,8 @@ def main():
             workload = f"PP direct summation fp64, N={n_side}^3, periodic box"
         value = pairs_per_step * args.steps / elapsed / 1e9
         # dominant kernel on rank 0's share: algorithmic flops of one launch / its duration
-        my_pairs = pairs_per_step / world if use_pairs else pairs_per_step * (counts[0] / n)
+        pair_shares = use_pairs if mg is None else bool(mg.stats()["pair_shares"])
+        my_pairs = pairs_per_step / world if pair_shares else pairs_per_step * (counts[0] / n)
         kernel_names = {1: "k_pairs (ordered pairs)", 2: "k_pairs (per-pair wrap)",
                         3: "k_p3m_cells", 4: "k_pairs (P3M, all pairs)",
                         5: "k_pairs_sym (each unordered pair once, both directions)"}
@@ -364,6 +418,20 @@ def main():
                          "subtiles_wrapped_frac": (st.get("subtiles_wrapped", 0) /
                                                    max(1, st.get("subtiles_total", 0)))},
         }
+        if world > 1 or mg is not None:
+            if mg is not None:
+                ag, rs, cp = (float(np.mean([c[k] for c in comm_ms])) for k in range(3))
+                st_mg = mg.stats()
+                line["config"]["parallelism"] = (
+                    f"block partition x{world}, libnbmg: ncclAllGather of positions per evaluation, "
+                    + ("shares of the unordered pairs + ncclReduceScatter" if pair_shares
+                       else "own targets against all sources, no reduction"))
+                line["comm"] = {"backend": "RCCL via libnbmg (C ABI)", "allgather_ms": ag, "reduce_scatter_ms": rs,
+                                "compute_ms": cp, "allgather_bytes_per_rank": st_mg["allgather_bytes"],
+                                "reduce_bytes_per_rank": st_mg["reduce_bytes"], "rank": 0}
+            else:
+                line["comm"] = {"backend": "gloo (rehearsal)" if rehearsal else "RCCL via torch.distributed",
+                                "note": comm_note}
         if mesh is not None:
             line["config"]["mesh_force_ms"] = float(np.mean(mesh_ms[args.warmup:]))
         if not args.no_cpu_baseline and world == 1:
@@ -389,6 +457,10 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if mg is not None:
+        torch.cuda.synchronize()
+        mg.shutdown()
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -445,3 +445,128 @@ def load_gas(device=None):
     if device is not None and not _GAS_LIB._inited:
         _GAS_LIB.init(device)
     return _GAS_LIB
+
+
+# ---------------------------------------------------------------------------------------
+# libnbmg.so: the multi-GPU layer (one process per GPU, RCCL), include/nbmg.h
+# ---------------------------------------------------------------------------------------
+MG_LIB_PATH = os.environ.get("NBMG_LIB") or os.path.join(HERE, "lib", "libnbmg.so")
+
+MG_EXPORTS = (
+    "nbmg_get_unique_id", "nbmg_init", "nbmg_init_from_env", "nbmg_shutdown", "nbmg_last_error",
+    "nbmg_rank", "nbmg_nranks", "nbmg_set_option", "nbmg_get_stats", "nbmg_partition",
+    "nbmg_padded_length", "nbmg_allgather_device", "nbmg_allreduce_sum_device",
+    "nbmg_allreduce_max_device", "nbmg_accumulate_device", "nbmg_max_accel_sq_device",
+)
+MG_UNIQUE_ID_BYTES = 128
+MG_OPT_TIMING, MG_OPT_PAIR_SHARES = 1, 2
+
+
+class MultiGpuStats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("allgather_ms", "compute_ms", "reduce_ms", "total_ms")] + [
+        ("allgather_bytes", C.c_uint64), ("reduce_bytes", C.c_uint64),
+        ("pair_shares", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MultiGpuLibrary:
+    """Loaded libnbmg.so.  Construction fails loudly when the shared object is missing."""
+
+    def __init__(self, path=MG_LIB_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it with `make -C nbody_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path")
+        try:  # one HIP runtime and one RCCL per process: torch's, when torch is in the process
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        Library()   # libnbpp.so first, from the same directory
+        L = self.lib = C.CDLL(path)
+        self.path = path
+        SZ = C.POINTER(C.c_size_t)
+        L.nbmg_get_unique_id.argtypes = [C.c_void_p]
+        L.nbmg_init.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.nbmg_shutdown.restype = None
+        L.nbmg_last_error.restype = C.c_char_p
+        L.nbmg_set_option.argtypes = [C.c_int, C.c_int64]
+        L.nbmg_get_stats.argtypes = [C.POINTER(MultiGpuStats)]
+        L.nbmg_partition.argtypes = [C.c_size_t, C.c_int, C.c_int, SZ, SZ]
+        L.nbmg_padded_length.argtypes = [C.c_size_t, C.c_int]
+        L.nbmg_padded_length.restype = C.c_size_t
+        L.nbmg_allgather_device.argtypes = [C.c_size_t, _DP, _DP, C.c_void_p]
+        L.nbmg_allreduce_sum_device.argtypes = [C.c_size_t, _DP, C.c_void_p]
+        L.nbmg_allreduce_max_device.argtypes = [C.c_size_t, _DP, C.c_void_p]
+        L.nbmg_accumulate_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7 + [C.c_void_p]
+        L.nbmg_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
+        self._inited = False
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NbppError(rc, self.lib.nbmg_last_error().decode(errors="replace"))
+
+    # lifecycle -------------------------------------------------------------------
+    def unique_id(self) -> bytes:
+        buf = C.create_string_buffer(MG_UNIQUE_ID_BYTES)
+        self._check(self.lib.nbmg_get_unique_id(buf))
+        return buf.raw
+
+    def init(self, rank=0, nranks=1, unique_id=None, device=0):
+        buf = C.create_string_buffer(unique_id, MG_UNIQUE_ID_BYTES) if unique_id is not None else None
+        self._check(self.lib.nbmg_init(rank, nranks, buf, device))
+        self._inited = True
+        return self
+
+    def shutdown(self):
+        self.lib.nbmg_shutdown()
+        self._inited = False
+
+    def set_option(self, key, value):
+        self._check(self.lib.nbmg_set_option(key, int(value)))
+
+    def stats(self):
+        s = MultiGpuStats()
+        self._check(self.lib.nbmg_get_stats(C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+
+    # partition (no GPU needed) ------------------------------------------------------
+    def partition(self, n, rank, nranks):
+        b, c = C.c_size_t(), C.c_size_t()
+        self._check(self.lib.nbmg_partition(n, rank, nranks, C.byref(b), C.byref(c)))
+        return b.value, c.value
+
+    def padded_length(self, n, nranks):
+        return self.lib.nbmg_padded_length(n, nranks)
+
+    # collectives and the force ---------------------------------------------------------
+    def allgather_device(self, n, own, full, stream=None):
+        self._check(self.lib.nbmg_allgather_device(n, _dev(own), _dev(full), C.c_void_p(stream or 0)))
+
+    def allreduce_sum_device(self, data, stream=None):
+        self._check(self.lib.nbmg_allreduce_sum_device(data.numel(), _dev(data), C.c_void_p(stream or 0)))
+
+    def allreduce_max_device(self, data, stream=None):
+        self._check(self.lib.nbmg_allreduce_max_device(data.numel(), _dev(data), C.c_void_p(stream or 0)))
+
+    def accumulate_device(self, p, n, own_x, own_y, own_z, m_full, ax, ay, az, stream=None):
+        """a[own] += PP force of all n particles on this rank's block (nbmg_accumulate_device)."""
+        self._check(self.lib.nbmg_accumulate_device(
+            C.byref(p), n, _dev(own_x), _dev(own_y), _dev(own_z), _dev(m_full), _dev(ax), _dev(ay),
+            _dev(az), C.c_void_p(stream or 0)))
+
+    def max_accel_sq_device(self, a, count=None, stream=None):
+        out = C.c_double(0.0)
+        n = a[0].numel() if count is None else count
+        self._check(self.lib.nbmg_max_accel_sq_device(n, _dev(a[0]), _dev(a[1]), _dev(a[2]), C.byref(out),
+                                                      C.c_void_p(stream or 0)))
+        return out.value
+
+
+_MG_LIB = None
+
+
+def load_multi_gpu():
+    """Process-wide MultiGpuLibrary (not initialised: call .init(rank, nranks, id, device))."""
+    global _MG_LIB
+    if _MG_LIB is None:
+        _MG_LIB = MultiGpuLibrary()
+    return _MG_LIB

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/nbgas.h"
+#include "../../include/nbmg.h"
 #include "../../include/nbpm.h"
 #include "../../include/nbpp.h"
 

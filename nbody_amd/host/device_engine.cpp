@@ -22,18 +22,32 @@ void nbpm_check(int rc) {
 void nbgas_check(int rc) {
     if (rc != NBGAS_OK) throw std::runtime_error(std::string("libnbgas: ") + nbgas_last_error());
 }
+void nbmg_check(int rc) {
+    if (rc != NBMG_OK) throw std::runtime_error(std::string("libnbmg: ") + nbmg_last_error());
+}
 }  // namespace
 
 DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const ZeldovichField* field)
     : config_(config) {
-    n_ = s.num_particles;
+    n_ = n_total_ = s.num_particles;
+    ranks_ = nbmg_nranks();
+    std::size_t padded = std::max<std::size_t>(n_total_, 1);
+    if (ranks_ > 0) {
+        nbmg_check(nbmg_partition(n_total_, nbmg_rank(), ranks_, &begin_, &n_));
+        padded = std::max<std::size_t>(nbmg_padded_length(n_total_, ranks_), 1);
+    }
     cells_ = static_cast<std::size_t>(config_.MESH_SIZE) * config_.MESH_SIZE * config_.MESH_SIZE;
     const std::vector<double>* host[10] = {&s.pos_x, &s.pos_y, &s.pos_z, &s.vel_x, &s.vel_y,
                                            &s.vel_z, &s.acc_x, &s.acc_y, &s.acc_z, &s.mass};
-    for (int c = 0; c < 10; ++c) {
+    for (int c = 0; c < 9; ++c) {      // this process's block of the per-particle state
         hip_check(hipMalloc(reinterpret_cast<void**>(&dev_[c]), sizeof(double) * std::max<std::size_t>(n_, 1)), "hipMalloc");
-        if (n_) hip_check(hipMemcpy(dev_[c], host[c]->data(), sizeof(double) * n_, hipMemcpyHostToDevice), "upload");
+        if (n_) hip_check(hipMemcpy(dev_[c], host[c]->data() + begin_, sizeof(double) * n_, hipMemcpyHostToDevice), "upload");
     }
+    // masses of ALL particles (the sources of the pair force), in a padded array
+    hip_check(hipMalloc(reinterpret_cast<void**>(&dev_[9]), sizeof(double) * padded), "hipMalloc");
+    hip_check(hipMemset(dev_[9], 0, sizeof(double) * padded), "hipMemset");
+    if (n_total_) hip_check(hipMemcpy(dev_[9], s.mass.data(), sizeof(double) * n_total_, hipMemcpyHostToDevice), "upload");
+    if (ranks_ > 1) hip_check(hipMalloc(reinterpret_cast<void**>(&gather_), sizeof(double) * padded), "hipMalloc");
     int device = 0;
     hip_check(hipGetDevice(&device), "hipGetDevice");
     // One stream of the engine's own for everything: the three libraries would otherwise each fall
@@ -41,7 +55,9 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
     // null stream), with nothing ordering one library's kernels after another's.
     hip_check(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&main_), hipStreamNonBlocking), "hipStreamCreate");
     for (void*& e : ev_) hip_check(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)), "hipEventCreate");
-    if (config_.USE_PM && config_.USE_PP && n_) {
+    // (not with several ranks: the collectives of one communicator must be issued in one order,
+    // which two streams do not give)
+    if (config_.USE_PM && config_.USE_PP && n_ && ranks_ <= 1) {
         hip_check(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&pp_stream_), hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pos_), hipEventDisableTiming), "hipEventCreate");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pp_), hipEventDisableTiming), "hipEventCreate");
@@ -58,16 +74,15 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
     if (config_.USE_HYDRO) {                                                 // src/ics.cpp:241-288
         if (!field || field->dx.size() != cells_)
             throw std::runtime_error("USE_HYDRO needs the displacement field of the initial conditions");
-        if (n_ == 0) throw std::runtime_error("USE_HYDRO needs dark-matter particles (src/ics.cpp:250)");
+        if (n_total_ == 0) throw std::runtime_error("USE_HYDRO needs dark-matter particles (src/ics.cpp:250)");
         nbgas_check(nbgas_init(device));
         for (double*& m : gas_) hip_check(hipMalloc(reinterpret_cast<void**>(&m), sizeof(double) * cells_), "hipMalloc");
-        const nbpm_params mp = config_.mesh_params();
-        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], main_));
+        deposit_density();
         // the displacement field is only needed now: stage it in the gravity meshes
         const std::vector<double>* disp[3] = {&field->dx, &field->dy, &field->dz};
         for (int c = 0; c < 3; ++c)
             hip_check(hipMemcpy(mesh_[2 + c], disp[c]->data(), sizeof(double) * cells_, hipMemcpyHostToDevice), "upload");
-        const double total_dm_mass = n_ * config_.DM_PARTICLE_MASS;          // :251-252
+        const double total_dm_mass = n_total_ * config_.DM_PARTICLE_MASS;    // :251-252
         const double mass_ratio = config_.GAS_TOTAL_MASS / total_dm_mass;
         const double u0 = internal_energy_from_temperature(config_.INITIAL_GAS_TEMPERATURE_K, config_.HUBBLE_PARAM,
                                                            config_.BOX_SIZE_MPC, config_.DOMAIN_SIZE, config_.GAMMA);
@@ -93,6 +108,7 @@ DeviceEngine::~DeviceEngine() {
         if (p) (void)hipFree(p);
     for (double* p : dev_)
         if (p) (void)hipFree(p);
+    if (gather_) (void)hipFree(gather_);
     for (double* p : gas_)
         if (p) (void)hipFree(p);
     for (double* p : mesh_)
@@ -103,13 +119,21 @@ nbgas_state DeviceEngine::gas_state() const {
     return nbgas_state{gas_[0], gas_[1], gas_[2], gas_[3], gas_[4], gas_[5], gas_[6], gas_[7], gas_[8]};
 }
 
+// bin_and_assign_mass's density (src/particles.cpp:47-100) of ALL particles into mesh_[0]: this
+// process's block, then the sum over the processes.
+void DeviceEngine::deposit_density() {
+    const nbpm_params mp = config_.mesh_params();
+    nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9] + begin_, mesh_[0], main_));
+    if (ranks_ > 1) nbmg_check(nbmg_allreduce_sum_device(cells_, mesh_[0], main_));
+}
+
 void DeviceEngine::compute_accelerations() {
     hipStream_t ms = static_cast<hipStream_t>(main_);
     if (config_.USE_PM || config_.USE_HYDRO) {                               // :239-245
         // bin_and_assign_mass, total density, Poisson solve; the gas kick reads the meshes too
         const nbpm_params mp = config_.mesh_params();
         if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), ms), "event");
-        nbpm_check(nbpm_deposit_device(&mp, n_, dev_[0], dev_[1], dev_[2], dev_[9], mesh_[0], main_));
+        deposit_density();
         const double* source = mesh_[0];
         if (config_.USE_HYDRO) {                                             // :57-59
             const nbgas_params gp = config_.gas_params();
@@ -149,6 +173,17 @@ void DeviceEngine::compute_accelerations() {
         hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pp_), pps), "event");
         hip_check(hipStreamWaitEvent(ms, static_cast<hipEvent_t>(ev_pp_), 0), "wait");
         nbpp_check(nbpp_add_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2], main_));
+    } else if (config_.USE_PP && n_total_ && ranks_ > 0) {                   // :254-258, over the ranks
+        const nbpp_params p = config_.pp_params();
+        nbpp_check(nbpp_set_option(NBPP_OPT_TIMING, 0));
+        nbmg_check(nbmg_set_option(NBMG_OPT_TIMING, timed_ ? 1 : 0));
+        nbmg_check(nbmg_accumulate_device(&p, n_total_, dev_[0], dev_[1], dev_[2], dev_[9], dev_[6], dev_[7],
+                                          dev_[8], main_));
+        nbmg_stats st;
+        if (timed_ && nbmg_get_stats(&st) == NBMG_OK) {
+            pp_ms += st.total_ms;
+            comm_ms += st.allgather_ms + st.reduce_ms;
+        }
     } else if (config_.USE_PP && n_) {                                       // :254-258
         const nbpp_params p = config_.pp_params();
         nbpp_check(nbpp_set_option(NBPP_OPT_TIMING, timed_ ? 1 : 0));
@@ -159,7 +194,9 @@ void DeviceEngine::compute_accelerations() {
     }
     pos_event_recorded_ = false;
     if (timed_) ++timed_force_calls;
-    if (!config_.STANDING_PARTICLES) {                                       // :261-262
+    if (!config_.STANDING_PARTICLES && ranks_ > 0) {                         // :261-262, over the ranks
+        nbmg_check(nbmg_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, main_));
+    } else if (!config_.STANDING_PARTICLES) {
         nbpp_check(nbpp_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, main_));
     } else {                                                                 // :263-269
         nbpp_check(nbpp_max_accel_sq_device(0, nullptr, nullptr, nullptr, &max_accel_sq, main_));
@@ -171,7 +208,7 @@ void DeviceEngine::compute_accelerations() {
 }
 
 double DeviceEngine::gravity_timestep() const {
-    if (n_ == 0) return std::numeric_limits<double>::infinity();
+    if (n_total_ == 0) return std::numeric_limits<double>::infinity();
     return std::sqrt(config_.SOFTENING_SQUARED) / std::sqrt(max_accel_sq) * config_.GRAVITY_DT_FACTOR;
 }
 
@@ -262,10 +299,17 @@ void DeviceEngine::download(ParticleSystem& out) {
                                      &out.vel_z, &out.acc_x, &out.acc_y, &out.acc_z, &out.mass};
     hip_check(hipDeviceSynchronize(), "sync");
     for (int c = 0; c < 10; ++c) {
-        host[c]->resize(n_);
-        if (n_) hip_check(hipMemcpy(host[c]->data(), dev_[c], sizeof(double) * n_, hipMemcpyDeviceToHost), "download");
+        host[c]->resize(n_total_);
+        if (!n_total_) continue;
+        const double* from = dev_[c];
+        if (ranks_ > 1 && c < 9) {      // every rank ends up with the whole state (collective)
+            nbmg_check(nbmg_allgather_device(n_total_, dev_[c], gather_, main_));
+            hip_check(hipStreamSynchronize(static_cast<hipStream_t>(main_)), "sync");
+            from = gather_;
+        }
+        hip_check(hipMemcpy(host[c]->data(), from, sizeof(double) * n_total_, hipMemcpyDeviceToHost), "download");
     }
-    out.num_particles = n_;
+    out.num_particles = n_total_;
     out.max_accel_sq = max_accel_sq;
 }
 

@@ -4,6 +4,15 @@
 // and libnbgas (gas).  Positions, velocities, accelerations and the gas meshes cross PCIe once in
 // each direction (upload at construction, download on request) instead of twice per step.
 // No snapshots, no logging.
+//
+// Several GPUs: when libnbmg has been initialised before the engine is built (nbmg_init /
+// nbmg_init_from_env, one process per GPU), every process constructs the engine from the SAME
+// initial state and keeps only its own block of the particles (nbmg_partition) in HBM; each force
+// phase all-gathers the positions (RCCL) inside nbmg_accumulate_device, the dark-matter density is
+// deposited per block and summed over the ranks, and the mesh solve and the gas, which are small
+// next to the pair force, are computed redundantly on every rank from identical inputs.  step(),
+// download() and the time-step functions are then collective: every rank must call them in the
+// same order.
 #pragma once
 #include <cstddef>
 #include <vector>
@@ -55,6 +64,8 @@ class DeviceEngine {
     double pp_ms = 0.0;                  // device time of the timed PP force calls
     double pm_ms = 0.0;                  // device time of the timed mesh force calls
     double gas_ms = 0.0;                 // device time of the timed gas sweeps
+    double comm_ms = 0.0;                // part of pp_ms spent in the position all-gathers and the
+                                         // reduce-scatters (several GPUs)
     // On cycles that are not timed, the short-range force runs on a stream of its own (into
     // arrays of its own, from zero) while the gas sweeps and the mesh force run on the main one;
     // the two are added at the end, which rounds exactly as accumulating onto the mesh force does
@@ -64,11 +75,15 @@ class DeviceEngine {
 
    private:
     void compute_accelerations();        // src/integrator.cpp:236-269
+    void deposit_density();
     double next_timestep();              // src/engine.cpp:16-22, :47-51
     nbgas_state gas_state() const;
     Config config_;
-    std::size_t n_ = 0, cells_ = 0;
-    double* dev_[10] = {};               // x y z vx vy vz ax ay az m
+    std::size_t n_ = 0, cells_ = 0;      // particles held by this process, mesh cells
+    std::size_t n_total_ = 0, begin_ = 0;   // all particles; index of this process's first one
+    int ranks_ = 0;                      // 0: libnbmg not in use; else the number of processes
+    double* dev_[10] = {};               // x y z vx vy vz ax ay az (own block) and m (ALL particles)
+    double* gather_ = nullptr;           // several ranks: one padded all-particle array for download()
     double* gas_[9] = {};                // GasGrid's meshes, in nbgas_state order
     double* mesh_[5] = {};               // dm density, total density, gravity x y z
     bool stop_requested_ = false;

@@ -8,7 +8,9 @@
 //                                          PP-only KDK steps on particles read from in.bin
 //                                          (dt <= 0: the engine's adaptive time step)
 //   nbody_host_tests ics <ini> <out.bin>   Zel'dovich particles of <ini> (x y z vx vy vz), GPU FFT
-//   nbody_host_tests run <ini> <cycles>    ICs + device-resident engine for <cycles> steps
+//   nbody_host_tests run <ini> <cycles>    ICs + device-resident engine for <cycles> steps; started
+//                                          once per GPU by a launcher that sets WORLD_SIZE, RANK
+//                                          and LOCAL_RANK, the processes share the particles
 //   nbody_host_tests engine <in.bin> <out.bin> <steps> <dt> <ini>
 //                                          the same steps with the state resident on the GPU
 #include <chrono>
@@ -288,7 +290,11 @@ int main(int argc, char** argv) {
         if (argc >= 4 && !std::strcmp(argv[1], "run")) {
             // run <ini> <cycles> [snapshot directory (HDF5) or file prefix (raw) [diagnostics.csv
             // directory [cycles between device-time samples]]]
-            if (nbpp_init(0) != NBPP_OK) { std::printf("nbpp_init failed: %s\n", nbpp_last_error()); return 2; }
+            // one process per GPU when a launcher set WORLD_SIZE / RANK / LOCAL_RANK (libnbmg),
+            // else GPU 0 alone
+            if (std::getenv("WORLD_SIZE")) {
+                if (nbmg_init_from_env() != NBMG_OK) { std::printf("nbmg_init_from_env failed: %s\n", nbmg_last_error()); return 2; }
+            } else if (nbpp_init(0) != NBPP_OK) { std::printf("nbpp_init failed: %s\n", nbpp_last_error()); return 2; }
             Config config;
             config.load(argv[2]);
             config.MAX_CYCLES = std::atoi(argv[3]);
@@ -305,6 +311,7 @@ int main(int argc, char** argv) {
             sim.print_timing(st);
             nbgas_shutdown();
             nbpm_shutdown();
+            nbmg_shutdown();
             nbpp_shutdown();
             return 0;
         }

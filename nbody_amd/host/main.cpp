@@ -10,6 +10,7 @@
 // outputs/run_<timestamp>/snapshot_%04d.bin instead, and the run says so.
 #include <csignal>
 #include <cstdio>
+#include <cstdlib>
 #include <ctime>
 #include <filesystem>
 #include <stdexcept>
@@ -61,7 +62,10 @@ int main(int argc, char** argv) {
     }
 
     try {
-        if (nbpp_init(0) != NBPP_OK) throw std::runtime_error(nbpp_last_error());
+        // one process per GPU when a launcher set WORLD_SIZE / RANK / LOCAL_RANK, else GPU 0 alone
+        if (std::getenv("WORLD_SIZE")) {
+            if (nbmg_init_from_env() != NBMG_OK) throw std::runtime_error(nbmg_last_error());
+        } else if (nbpp_init(0) != NBPP_OK) throw std::runtime_error(nbpp_last_error());
         RunOptions options;
         options.log_dir = run_dir;
         options.progress = false;
@@ -91,11 +95,13 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "\n[FATAL] Simulation crashed: %s\n", e.what());      // :85-87
         nbgas_shutdown();
         nbpm_shutdown();
+        nbmg_shutdown();
         nbpp_shutdown();
         return 1;
     }
     nbgas_shutdown();
     nbpm_shutdown();
+    nbmg_shutdown();
     nbpp_shutdown();
     return 0;
 }

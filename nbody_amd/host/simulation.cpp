@@ -10,6 +10,8 @@
 
 namespace nbh {
 
+static bool writer_rank();
+
 Simulation::Simulation(const Config& config, const RunOptions& options) : config_(config), options_(options) {
     Cosmology cosmo;
     ZeldovichField field;
@@ -19,17 +21,22 @@ Simulation::Simulation(const Config& config, const RunOptions& options) : config
     engine_->timing_every = options_.timing_every >= 0
                                 ? options_.timing_every
                                 : std::max(1, std::min(config_.DEBUG_INFO_EVERY_CYCLES, config_.MAX_CYCLES));
-    if (!options_.snapshot_target.empty() && std::filesystem::is_directory(options_.snapshot_target))
+    if (writer_rank() && !options_.snapshot_target.empty() && std::filesystem::is_directory(options_.snapshot_target))
         hdf5_.reset(new SnapshotWriter(options_.snapshot_target, config_));
-    if (!options_.log_dir.empty()) logger_.reset(new Logger(options_.log_dir));
+    if (writer_rank() && !options_.log_dir.empty()) logger_.reset(new Logger(options_.log_dir));
     next_output_a_ = config_.START_A + config_.SAVE_HDF5_EVERY_DELTA_A;
     logged_wall_ = std::chrono::steady_clock::now();
 }
+
+// With several processes (libnbmg) every one of them downloads, since that is a collective
+// operation, and the first alone prints and writes.
+static bool writer_rank() { return nbmg_rank() <= 0; }
 
 void Simulation::report(const char* when) {
     DeviceEngine& engine = *engine_;
     ParticleSystem now(config_);
     engine.download(now);
+    if (!writer_rank()) return;
     std::printf("%s: cycle %ld a=%.17g dt=%.17g max|a|^2=%.17g\n", when, engine.cycle_count,
                 engine.cosmo.scale_factor, engine.current_dt, engine.max_accel_sq);
     if (now.num_particles)
@@ -51,6 +58,10 @@ void Simulation::save_snapshot() {
     engine.download(now);
     std::vector<double> gas[9];
     engine.download_gas(gas);
+    if (!writer_rank()) {
+        ++snapshot_count_;
+        return;
+    }
     if (hdf5_) {
         hdf5_->save_snapshot(snapshot_count_++, engine.cycle_count, now, gas, engine.cosmo.total_time,
                              engine.cosmo.scale_factor, config_);
@@ -74,10 +85,11 @@ void Simulation::save_snapshot() {
 }
 
 void Simulation::log_diagnostics() {
-    if (!logger_ || !logger_->is_open()) return;
+    if (options_.log_dir.empty()) return;
     DeviceEngine& engine = *engine_;
     ParticleSystem now(config_);
     engine.download(now);
+    if (!logger_ || !logger_->is_open()) return;
     std::vector<double> gas[9], total_rho, phi;
     engine.download_gas(gas);
     engine.download_mesh_solve(total_rho, phi);
@@ -146,6 +158,10 @@ ExitStatus Simulation::run(const volatile std::sig_atomic_t* stop) {
 
 void Simulation::print_timing(ExitStatus status) const {
     const DeviceEngine& engine = *engine_;
+    if (!writer_rank()) return;
+    if (nbmg_nranks() > 1)
+        std::printf("ranks: %d processes, one GPU each; of the PP time %.3f ms/cycle is all-gather and reduce-scatter\n",
+                    nbmg_nranks(), engine.comm_ms / std::max(1L, engine.timed_force_calls));
     std::printf("timing: %ld cycles, %.3f ms/cycle wall; PP %.3f, mesh %.3f, hydro sweeps %.3f ms/cycle (device, %ld timed cycles); exit=%d\n",
                 engine.cycle_count, run_wall_ms_ / std::max(1L, engine.cycle_count),
                 engine.pp_ms / std::max(1L, engine.timed_force_calls), engine.pm_ms / std::max(1L, engine.timed_force_calls),

@@ -66,6 +66,41 @@ def test_gas_header_and_library_agree():
             L.init(0)                     # no device: fails loudly, no CPU path
 
 
+def test_multi_gpu_header_and_library_agree():
+    names = _declared("nbmg.h", "nbmg_")
+    assert len(names) >= 14
+    lib = ctypes.CDLL(ffi.LIB_PATH, mode=ctypes.RTLD_GLOBAL)   # libnbmg.so needs libnbpp.so
+    lib = ctypes.CDLL(ffi.MG_LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nbmg.h but not exported"
+    assert sorted(ffi.MG_EXPORTS) == names
+    assert ctypes.sizeof(ffi.MultiGpuStats) == 4 * 8 + 2 * 8 + 2 * 4
+    L = ffi.MultiGpuLibrary()
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(ffi.NbppError):
+            L.init(0, 1, None, 0)          # no device: fails loudly, no CPU path
+        assert L.lib.nbmg_rank() == -1 and L.lib.nbmg_nranks() == 0
+
+
+def test_multi_gpu_partition_is_blocks_of_the_padded_layout():
+    """nbmg_partition: rank r owns [r * stride, min(n, (r + 1) * stride)), stride = ceil(n / nranks),
+    so a padded array in global order is rank-major blocks and collectives need no repacking."""
+    L = ffi.MultiGpuLibrary()
+    for n, w in ((10, 3), (8, 8), (2097152, 8), (16777216, 8), (5, 8), (0, 2), (1001, 2)):
+        stride = -(-n // w)
+        assert L.padded_length(n, w) == stride * w
+        covered = 0
+        for r in range(w):
+            b, c = L.partition(n, r, w)
+            assert b == min(n, r * stride) and c == min(stride, n - b)
+            assert b == covered or c == 0
+            covered += c
+        assert covered == n
+    with pytest.raises(ffi.NbppError):
+        L.partition(10, 3, 3)
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(ffi.Params) == 9 * 8 + 2 * 4
     assert ctypes.sizeof(ffi.Stats) == 5 * 8 + 7 * 8 + 2 * 4

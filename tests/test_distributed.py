@@ -90,6 +90,69 @@ def test_two_rank_partition_matches_single_process(tmp_path, oracle, n, use_pm):
     assert np.array_equal(got, want)  # same oracle, same order per target: bitwise
 
 
+def _native_worker(rank, world, port, n, out_dir):
+    """The block partition of libnbmg (nbmg_partition / nbmg_padded_length, the C++ code the GPU
+    path runs) driving the same sequence of collectives as nbmg_accumulate_device, with gloo
+    standing in for RCCL: in-place all-gather of whole blocks of a padded array, each rank's
+    targets against all sources, and for direct summation the pair-share variant (full-length
+    partial sums, reduce-scatter of whole blocks, add)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datasets
+    from nbody_amd import Config, ffi
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    mg = ffi.MultiGpuLibrary()
+    begin, count = mg.partition(n, rank, world)
+    padded = mg.padded_length(n, world)
+    stride = padded // world
+    pos = datasets.clustered(n)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=8, N_PER_SIDE=8, USE_PM=False).pp_params()
+    own = [torch.from_numpy(c[begin:begin + count].copy()) for c in pos]
+    full = [torch.full((padded,), float("nan"), dtype=torch.float64) for _ in range(3)]
+    for c in range(3):
+        full[c][begin:begin + count] = own[c]
+        dist.all_gather_into_tensor(full[c], full[c][rank * stride:(rank + 1) * stride].clone())
+        assert np.array_equal(full[c][:n].numpy(), pos[c])
+    x, y, z = (f[:n].numpy() for f in full)
+    acc = orc.accumulate(p, x, y, z, m, tgt_begin=begin, n_tgt=count, nthreads=2)
+    # pair shares: this rank contributes the forces from the sources of ITS block on everybody
+    sums = [torch.zeros(padded, dtype=torch.float64) for _ in range(3)]
+    mm = np.zeros(n)
+    mm[begin:begin + count] = m[begin:begin + count]
+    part = orc.accumulate(p, x, y, z, mm, nthreads=2)
+    for c in range(3):
+        sums[c][:n] = torch.from_numpy(part[c])
+        dist.all_reduce(sums[c])                      # gloo has no reduce-scatter: keep the own block
+    acc2 = [s[rank * stride: rank * stride + count].numpy() for s in sums]
+    np.save(os.path.join(out_dir, f"native_{rank}.npy"), np.stack(acc))
+    np.save(os.path.join(out_dir, f"native_pairs_{rank}.npy"), np.stack(acc2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1001, 1000])
+def test_two_rank_native_block_partition(tmp_path, oracle, n):
+    port = _free_port()
+    mp.spawn(_native_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datasets
+    from nbody_amd import Config
+    pos = datasets.clustered(n)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=8, N_PER_SIDE=8, USE_PM=False).pp_params()
+    want = np.stack(oracle.accumulate(p, *pos, m))
+    got = np.concatenate([np.load(tmp_path / f"native_{r}.npy") for r in range(2)], axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    got2 = np.concatenate([np.load(tmp_path / f"native_pairs_{r}.npy") for r in range(2)], axis=1)
+    norm = np.linalg.norm(want, axis=0)
+    assert np.max(np.abs(got2 - want) / norm) < 1e-12     # a different summation order
+
+
 def test_partition_shapes():
     from nbody_amd.distributed import partition
     for n, w in ((10, 3), (8, 8), (2097152, 8), (5, 8), (0, 2)):
