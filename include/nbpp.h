@@ -135,6 +135,20 @@ int nbpp_accumulate(const nbpp_params* p, size_t n,
                     double* ax, double* ay, double* az);
 
 /*
+ * Optional, for callers of nbpp_accumulate that keep their arrays for the whole run (the
+ * reference's std::vector members, src/particles.h:39-51): page-locked host memory for those
+ * arrays (e.g. behind a std::vector allocator).  nbpp_accumulate recognises page-locked arrays by
+ * itself (these, or anything from hipHostMalloc): positions and masses then travel by plain DMA,
+ * and the device adds its sums to page-locked accumulators in place, instead of returning them
+ * through a staging buffer and a host-side add.  Thin wrappers of hipHostMalloc / hipHostFree, so
+ * that the caller does not need the HIP headers; nbpp_host_alloc returns NULL on failure
+ * (nbpp_last_error() has the reason).  Replaces: nothing in the reference (its map(to/tofrom)
+ * clauses, src/particles.cpp:169-173, leave the staging to the OpenMP runtime).
+ */
+void* nbpp_host_alloc(size_t bytes);
+void nbpp_host_free(void* p);
+
+/*
  * Device-resident form of the same operation (replaces the per-call map(to/tofrom)
  * re-mapping of src/particles.cpp:169-173).  x,y,z,m are DEVICE pointers to n_src
  * sources.  Targets are the sub-range [tgt_begin, tgt_begin + n_tgt) of the sources
@@ -144,6 +158,10 @@ int nbpp_accumulate(const nbpp_params* p, size_t n,
  * HIP null stream, as for every HIP call) and is ordered like any other work on that stream; the
  * host returns once the pair kernel is queued (the P3M path waits once in between, for the number
  * of cell-list entries), or when it has finished if NBPP_OPT_TIMING is on.
+ * ax, ay, az may also be page-locked host memory that the device can reach (hipHostMalloc,
+ * hipHostRegister): the library then keeps to the kernels that write their sums with plain
+ * stores (the pair-once direct-summation kernel adds with fp64 atomics, which are only
+ * guaranteed for ordinary device allocations, and is not chosen for such outputs).
  */
 int nbpp_accumulate_device(const nbpp_params* p, size_t n_src,
                            const double* x, const double* y, const double* z,
@@ -179,8 +197,10 @@ int nbpp_accumulate_device_noalloc(const nbpp_params* p, size_t n,
  * ax, ay, az, which are DEVICE arrays of full length n in the caller's particle order.  The
  * sum of the arrays over all parts (e.g. an RCCL reduce-scatter) is the complete acceleration;
  * with n_parts == 1 the call is equivalent to nbpp_accumulate_device over all targets.
- * Uses fp64 atomics: not bitwise reproducible from run to run.  No counterpart in the
- * reference, which evaluates every ordered pair (src/particles.cpp:270-365).
+ * Uses fp64 atomics: not bitwise reproducible from run to run, and ax, ay, az must be ordinary
+ * device allocations (hipMalloc and the like): host-mapped or managed memory is rejected with
+ * NBPP_ERR_ARG, since hardware fp64 atomics are not guaranteed to land there.  No counterpart in
+ * the reference, which evaluates every ordered pair (src/particles.cpp:270-365).
  */
 int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n,
                                  const double* x, const double* y, const double* z,

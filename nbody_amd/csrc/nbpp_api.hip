@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/nbpp.h"
@@ -135,6 +136,8 @@ struct Ctx : Work {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* pinned = nullptr;           // 8 KiB of page-locked host memory: small read-backs land here without staging
     Arena fixed;                      // the device's copy of the fixed workspace (nbpp_accumulate_device_noalloc)
+    double* bounce = nullptr;         // page-locked host buffer the sums of nbpp_accumulate come back through
+    size_t bounce_bytes = 0;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
             opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0;
     nbpp_stats stats{};
@@ -145,6 +148,24 @@ std::mutex g_mu;
 
 inline int cdiv(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
 
+// What kind of memory a caller's pointer names.  fp64 atomics issued by a kernel are only
+// guaranteed to land in ordinary device allocations (hipMalloc and the like); page-locked host
+// memory (hipHostMalloc / hipHostRegister) is reachable from kernels by plain loads and stores.
+enum class Mem { Device, PinnedHost, Other };
+Mem classify(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // an address the runtime has never seen
+        return Mem::Other;
+    }
+    if (a.type == hipMemoryTypeDevice) return Mem::Device;
+    if (a.type == hipMemoryTypeHost) return Mem::PinnedHost;
+    return Mem::Other;             // managed, unregistered, array
+}
+bool all_device(const double* a, const double* b, const double* c) {
+    return classify(a) == Mem::Device && classify(b) == Mem::Device && classify(c) == Mem::Device;
+}
+
 int check_params(const nbpp_params* p) {
     if (!p) return fail(NBPP_ERR_ARG, "params is NULL");
     if (!(p->domain_size > 0.0) || !std::isfinite(p->domain_size))
@@ -152,10 +173,12 @@ int check_params(const nbpp_params* p) {
     if (!(p->soft_sq >= 0.0)) return fail(NBPP_ERR_ARG, "soft_sq must be >= 0");
     if (!std::isfinite(p->G)) return fail(NBPP_ERR_ARG, "G must be finite");
     if (p->use_pm) {
-        if (!(p->cutoff_sq > 0.0) || !(p->trans_width > 0.0) || !(p->pm_soft_sq >= 0.0) ||
+        // trans_width == 0 (cutoff_transition_width_factor = 0) is legal in the reference: r_switch
+        // then equals the cutoff radius and no accepted pair reaches the taper's division
+        if (!(p->cutoff_sq > 0.0) || !(p->trans_width >= 0.0) || !(p->pm_soft_sq >= 0.0) ||
             !(p->r_switch >= 0.0))
             return fail(NBPP_ERR_ARG,
-                        "use_pm needs cutoff_sq > 0, trans_width > 0, pm_soft_sq >= 0, "
+                        "use_pm needs cutoff_sq > 0, trans_width >= 0, pm_soft_sq >= 0, "
                         "r_switch >= 0");
     }
     return NBPP_OK;
@@ -170,7 +193,7 @@ PairConsts make_consts(const nbpp_params* p) {
     k.r_switch = p->r_switch;
     k.r_switch_sq = p->r_switch_sq;
     k.cutoff_sq = p->cutoff_sq;
-    k.inv_width = p->use_pm ? 1.0 / p->trans_width : 0.0;
+    k.inv_width = (p->use_pm && p->trans_width > 0.0) ? 1.0 / p->trans_width : 0.0;
     k.qscale = static_cast<double>(1 << QBITS) / p->domain_size;
     k.c15 = 1.5;
     k.c1875 = 1.875;
@@ -642,6 +665,14 @@ int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const
                             (g.opt_force_kernel == 0 && !g.opt_deterministic && n_src >= (1u << 14))))
             variant = NBPP_KERNEL_DIRECT_SYMMETRIC;
         if (sym_part >= 0) variant = NBPP_KERNEL_DIRECT_SYMMETRIC;
+        // that kernel adds to the outputs with fp64 atomics: only for ordinary device memory
+        if (variant == NBPP_KERNEL_DIRECT_SYMMETRIC && !all_device(ax, ay, az)) {
+            if (sym_part >= 0 || g.opt_force_kernel == NBPP_KERNEL_DIRECT_SYMMETRIC)
+                return fail(NBPP_ERR_ARG,
+                            "the pair-once kernel adds with fp64 atomics and needs ax, ay, az in ordinary "
+                            "device memory (hipMalloc), not host-mapped or managed memory");
+            variant = NBPP_KERNEL_DIRECT;
+        }
     }
     g.stats.kernel_variant = variant;
     if (g.opt_timing) HIPCHK(hipEventRecord(g.ev[0], s));
@@ -726,6 +757,9 @@ void nbpp_shutdown(void) {
     g.stream = nullptr;
     if (g.pinned) (void)hipHostFree(g.pinned);
     g.pinned = nullptr;
+    if (g.bounce) (void)hipHostFree(g.bounce);
+    g.bounce = nullptr;
+    g.bounce_bytes = 0;
     g.ready = false;
 }
 
@@ -810,6 +844,25 @@ int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n, const double* x
     return compute_on_device(p, n, x, y, z, m, 0, n, ax, ay, az, s, part, n_parts);
 }
 
+void* nbpp_host_alloc(size_t bytes) {
+    if (!g.ready) {
+        (void)fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+        return nullptr;
+    }
+    void* p = nullptr;
+    if (bytes == 0 || hipSetDevice(g.device) != hipSuccess ||
+        hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)fail(NBPP_ERR_NOMEM, "cannot allocate %zu bytes of page-locked host memory", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void nbpp_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const double* y,
                     const double* z, const double* m, double* ax, double* ay, double* az) {
     if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
@@ -820,18 +873,24 @@ int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const doubl
     HIPCHK(hipSetDevice(g.device));
     const size_t bytes = sizeof(double) * n;
     const double* hin[4] = {x, y, z, m};
-    hipEvent_t e0 = g.ev[3];
+    double* hout[3] = {ax, ay, az};
     for (int c = 0; c < 4; ++c) CHK(g.host_in[c].ensure(bytes));
     for (int c = 0; c < 3; ++c) CHK(g.host_acc[c].ensure(bytes));
+    // page-locked accumulators (nbpp_host_alloc, hipHostMalloc): the device adds its sums to
+    // them in place, through the bus; pageable ones: the sums come back through a page-locked
+    // buffer of the library's own and host threads add them
+    bool acc_pinned = true;
+    for (double* o : hout) acc_pinned = acc_pinned && classify(o) == Mem::PinnedHost;
     auto t0 = std::chrono::steady_clock::now();
+    // (from page-locked caller memory these are plain DMA transfers; from pageable memory the
+    // runtime stages them)
     for (int c = 0; c < 4; ++c)
         HIPCHK(hipMemcpyAsync(g.host_in[c].p, hin[c], bytes, hipMemcpyHostToDevice, g.stream));
-    // the device sums start from zero; the caller's accumulators are added on the host, which
+    // the device sums start from zero and are added to the caller's accumulators once, which
     // is the same single rounding as the reference's acc[i] += local (src/particles.cpp:362-364)
     for (int c = 0; c < 3; ++c) HIPCHK(hipMemsetAsync(g.host_acc[c].p, 0, bytes, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     auto t1 = std::chrono::steady_clock::now();
-    (void)e0;
     int rc = compute_on_device(p, n, g.host_in[0].as<double>(), g.host_in[1].as<double>(),
                                g.host_in[2].as<double>(), g.host_in[3].as<double>(), 0, n,
                                g.host_acc[0].as<double>(), g.host_acc[1].as<double>(),
@@ -839,12 +898,42 @@ int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const doubl
     if (rc != NBPP_OK) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
     auto t2 = std::chrono::steady_clock::now();
-    std::vector<double> tmp(n);
-    double* hout[3] = {ax, ay, az};
-    for (int c = 0; c < 3; ++c) {
-        HIPCHK(hipMemcpy(tmp.data(), g.host_acc[c].p, bytes, hipMemcpyDeviceToHost));
-        double* o = hout[c];
-        for (size_t i = 0; i < n; ++i) o[i] += tmp[i];
+    if (acc_pinned) {
+        double* dev_view[3];
+        for (int c = 0; c < 3; ++c)
+            HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view[c]), hout[c], 0));
+        const int blocks = std::min(4096, cdiv(static_cast<long long>(n), WG));
+        hipLaunchKernelGGL(k_add, dim3(blocks), dim3(WG), 0, g.stream, n, dev_view[0], dev_view[1], dev_view[2],
+                           g.host_acc[0].as<double>(), g.host_acc[1].as<double>(), g.host_acc[2].as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g.stream));
+    } else {
+        if (g.bounce_bytes < 3 * bytes) {
+            if (g.bounce) HIPCHK(hipHostFree(g.bounce));
+            g.bounce = nullptr;
+            g.bounce_bytes = 0;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g.bounce), 3 * bytes + 3 * bytes / 8, hipHostMallocDefault));
+            g.bounce_bytes = 3 * bytes + 3 * bytes / 8;
+        }
+        // one transfer per component; while component c + 1 is on the bus, host threads add c
+        for (int c = 0; c < 3; ++c) {
+            HIPCHK(hipMemcpyAsync(g.bounce + c * n, g.host_acc[c].p, bytes, hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipEventRecord(g.ev[c], g.stream));
+        }
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>({8, hw, n / 65536 + 1}));
+        for (int c = 0; c < 3; ++c) {
+            HIPCHK(hipEventSynchronize(g.ev[c]));
+            double* o = hout[c];
+            const double* t = g.bounce + c * n;
+            auto add = [o, t](size_t b, size_t e) { for (size_t i = b; i < e; ++i) o[i] += t[i]; };
+            std::vector<std::thread> pool;
+            const size_t chunk = (n + nthreads - 1) / nthreads;
+            for (size_t k = 1; k < nthreads; ++k)
+                pool.emplace_back(add, std::min(n, k * chunk), std::min(n, (k + 1) * chunk));
+            add(0, std::min(n, chunk));
+            for (auto& th : pool) th.join();
+        }
     }
     auto t3 = std::chrono::steady_clock::now();
     g.stats.h2d_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();

@@ -19,7 +19,8 @@ OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SE
 
 EXPORTS = (
     "nbpp_init", "nbpp_shutdown", "nbpp_last_error", "nbpp_set_option", "nbpp_get_stats",
-    "nbpp_accumulate", "nbpp_accumulate_device", "nbpp_accumulate_device_noalloc",
+    "nbpp_accumulate", "nbpp_host_alloc", "nbpp_host_free", "nbpp_accumulate_device",
+    "nbpp_accumulate_device_noalloc",
     "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device", "nbpp_add_device",
     "nbpp_max_accel_sq_device",
 )
@@ -91,6 +92,10 @@ class Library:
         L.nbpp_set_option.argtypes = [C.c_int, C.c_int64]
         L.nbpp_get_stats.argtypes = [C.POINTER(Stats)]
         L.nbpp_accumulate.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7
+        L.nbpp_host_alloc.argtypes = [C.c_size_t]
+        L.nbpp_host_alloc.restype = C.c_void_p
+        L.nbpp_host_free.argtypes = [C.c_void_p]
+        L.nbpp_host_free.restype = None
         L.nbpp_accumulate_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 4 + [
             C.c_size_t, C.c_size_t] + [_DP] * 3 + [C.c_void_p]
         L.nbpp_accumulate_device_noalloc.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7 + [
@@ -131,6 +136,17 @@ class Library:
         n = x.size
         self._check(self.lib.nbpp_accumulate(C.byref(p), n, _host(x), _host(y), _host(z),
                                              _host(m), _host(ax), _host(ay), _host(az)))
+
+    def host_alloc(self, n):
+        """float64[n] numpy view of page-locked host memory (nbpp_host_alloc); release it with
+        host_free(array) once nothing refers to it any more."""
+        ptr = self.lib.nbpp_host_alloc(max(n, 1) * 8)
+        if not ptr:
+            raise NbppError(-5, self.lib.nbpp_last_error().decode(errors="replace"))
+        return np.ctypeslib.as_array(C.cast(C.c_void_p(ptr), _DP), shape=(n,))
+
+    def host_free(self, a):
+        self.lib.nbpp_host_free(C.c_void_p(a.ctypes.data))
 
     def accumulate_device(self, p, x, y, z, m, ax, ay, az, tgt_begin=0, n_tgt=None,
                           stream=None):

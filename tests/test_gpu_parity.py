@@ -761,3 +761,83 @@ def test_randomised_configurations(lib, oracle, seed):
     torch.cuda.synchronize()
     sub = [w[begin:begin + count] for w in want]
     assert normalised_error([t.cpu().numpy() for t in part], sub, floor=floor) < TOL
+
+
+# --------------------------------------------------------------------------------------
+# where the outputs live: the pair-once kernel's fp64 atomics need ordinary device memory
+# --------------------------------------------------------------------------------------
+def _raw_call(lib, fn, p, n, x, y, z, m, extra, outs):
+    """An entry point called with bare addresses (page-locked host tensors are not CUDA tensors)."""
+    import ctypes as C
+    DP = C.POINTER(C.c_double)
+    ptr = lambda t: C.cast(C.c_void_p(t.data_ptr()), DP)          # noqa: E731
+    return fn(C.byref(p), n, ptr(x), ptr(y), ptr(z), ptr(m), *extra, *[ptr(o) for o in outs], C.c_void_p(0))
+
+
+def test_host_mapped_outputs_never_get_the_atomic_kernel(lib, oracle):
+    import torch
+    n_side = 26                                                  # 17 576 >= 2^14: the pair-once kernel's range
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side)
+    m = datasets.masses(n)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=False).pp_params()
+    x, y, z, mm = (torch.as_tensor(a, device="cuda:0") for a in (*pos, m))
+    outs = [torch.zeros(n, dtype=torch.float64).pin_memory() for _ in range(3)]    # hipHostMalloc
+    rc = _raw_call(lib, lib.lib.nbpp_accumulate_device, p, n, x, y, z, mm, (0, n), outs)
+    assert rc == 0, lib.lib.nbpp_last_error()
+    torch.cuda.synchronize()
+    assert lib.stats()["kernel_variant"] == ffi.KERNEL_DIRECT    # not KERNEL_DIRECT_SYMMETRIC
+    dev_outs = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    lib.accumulate_device(p, x, y, z, mm, *dev_outs)
+    assert lib.stats()["kernel_variant"] == ffi.KERNEL_DIRECT_SYMMETRIC
+    want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=512)
+    assert normalised_error([o.numpy()[:512] for o in outs], want) < TOL
+    assert normalised_error([o.cpu().numpy()[:512] for o in dev_outs], want) < TOL
+    # the entry point that is nothing but that kernel refuses such outputs
+    rc = _raw_call(lib, lib.lib.nbpp_accumulate_pairs_device, p, n, x, y, z, mm, (0, 1), outs)
+    assert rc == -1 and b"ordinary device memory" in lib.lib.nbpp_last_error()
+    lib.set_option(ffi.OPT_FORCE_KERNEL, ffi.KERNEL_DIRECT_SYMMETRIC)
+    try:
+        rc = _raw_call(lib, lib.lib.nbpp_accumulate_device, p, n, x, y, z, mm, (0, n), outs)
+        assert rc == -1
+    finally:
+        lib.set_option(ffi.OPT_FORCE_KERNEL, 0)
+
+
+@pytest.mark.parametrize("use_pm", [False, True])
+def test_page_locked_caller_arrays_give_the_same_sums(lib, use_pm):
+    """nbpp_accumulate from page-locked arrays (nbpp_host_alloc: DMA in, sums added in place by
+    the device) against the same call on pageable arrays (staged, added by host threads): the
+    same kernels and one rounding per accumulator either way, so bit for bit."""
+    n_side = 20
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side, seed=4)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm).pp_params()
+    start = [np.full(n, 0.25), np.full(n, -1.0), np.zeros(n)]
+    plain = gpu_acc(lib, p, pos, m, acc0=start)
+    arrays = [lib.host_alloc(n) for _ in range(7)]
+    try:
+        for dst, src in zip(arrays, (*pos, m, *start)):
+            dst[:] = src
+        lib.accumulate(p, *arrays)
+        for got, want in zip(arrays[4:], plain):
+            assert np.array_equal(got, want)
+    finally:
+        for a in arrays:
+            lib.host_free(a)
+
+
+def test_zero_transition_width_is_accepted(lib, oracle):
+    """cutoff_transition_width_factor = 0: r_switch equals the cutoff radius, so no accepted pair
+    reaches the taper (src/particles.cpp:331-335); the reference accepts the configuration."""
+    n_side = 16
+    pos = datasets.jittered_lattice(n_side, jitter=0.9)
+    m = datasets.masses(n_side ** 3)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True, CUTOFF_TRANSITION_WIDTH_FACTOR=0.0).pp_params()
+    assert p.trans_width == 0.0 and p.r_switch_sq == p.cutoff_sq
+    want = oracle.accumulate(p, *pos, m, traversal=O.EXACT_CELLS)
+    got = gpu_acc(lib, p, pos, m)
+    assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
+    assert all(np.all(np.isfinite(g)) for g in got)
+    assert normalised_error(got, want) < TOL
