@@ -13,6 +13,8 @@
 // one third-order correction (relative error ~3e-16 per pair).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 namespace nbpp {
@@ -1258,6 +1260,169 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
         unsigned long long h = live ? hits : 0u;
         for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(a.accepted, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The same search with the survivors of the filter POOLED per wavefront.
+//
+// In k_p3m_cells every lane drains its own ring, so a wavefront walks the drain loop as often as
+// its fullest lane needs: 85 iterations for a mean of 62-71 accepted pairs per target on a
+// near-uniform set, twice the balanced count once the particles have clustered.  Here the
+// filter is the same (one lane per target, P3M_TRIP candidates per trip), but every survivor goes
+// as a (target lane, source) pair into one ring per wavefront: for each of the P3M_TRIP candidate
+// slots the survivors of the 64 lanes are compacted with a ballot and a prefix count, so a slot's
+// batch holds every target at most once.  Whenever the ring holds 2 * 64 pairs the wavefront
+// evaluates them 64 at a time, two in flight per lane, one pair per lane whatever target it
+// belongs to: every lane of every drain step does the full arithmetic.  The lane reads its
+// pair's target position from a table in LDS and adds the pair's contribution to that target's
+// sums in LDS (ds_add_f64; a step's 64 pairs come from at most three batches, so few lanes
+// collide).  The order in which colliding lanes add is the hardware's: sums are not bitwise
+// reproducible from run to run (NBPP_OPT_DETERMINISTIC keeps k_p3m_cells).
+// ---------------------------------------------------------------------------------
+constexpr int P3M_POOL_CAP = 512;   // pairs per wavefront ring (power of 2): < 128 left by a drain + 4 * 64 from a trip
+
+template <bool SOFT0, bool WIDE>
+__global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
+    __shared__ uint2 pool[WG / 64][P3M_POOL_CAP];   // {target lane, sorted position of the source}
+    __shared__ double2 txy[WG];                      // target x, y
+    __shared__ double tz[WG];                        // target z
+    __shared__ double tsum[3][WG];                   // the targets' sums
+    const int b = static_cast<int>(blockIdx.x);      // XCD-aware order of the pieces: see k_p3m_cells
+    const int group = b / (8 * P3M_XCD_RUN);
+    const int in_group = b - group * (8 * P3M_XCD_RUN);
+    const bool whole = (group + 1) * (8 * P3M_XCD_RUN) <= static_cast<int>(gridDim.x);
+    const int piece = whole ? group * (8 * P3M_XCD_RUN) + (in_group % 8) * P3M_XCD_RUN + in_group / 8 : b;
+    const int t = piece * WG + threadIdx.x;
+    const bool live = t < a.n_tgt;
+    const int p = a.tlist[live ? t : a.n_tgt - 1];
+    const double4 me = a.rec[p];
+    const p3m_vf nmx = -a.fx[p], nmy = -a.fy[p], nmz = -a.fz[p];
+    const GhostGrid g = a.g;
+    const PairConsts k = a.k;
+    const float bound = a.prefilter_sq;
+    const int pcx = bin_coord(me.x, g.scale, g.nside) + g.R;
+    const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
+    const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wave_base = wave << 6;
+    uint2* const ring = pool[wave];
+    txy[threadIdx.x] = make_double2(me.x, me.y);
+    tz[threadIdx.x] = me.z;
+    tsum[0][threadIdx.x] = 0.0;
+    tsum[1][threadIdx.x] = 0.0;
+    tsum[2][threadIdx.x] = 0.0;
+    __builtin_amdgcn_wave_barrier();   // only this wavefront reads them back, and LDS operations of a wavefront stay in order
+    int rp = 0, wp = 0;                // ring read / write positions, unwrapped, the same in every lane
+    unsigned hits = 0;
+    const uint32_t f_bytes = WIDE ? 0u : static_cast<uint32_t>(a.n_entries + P3M_TRIP) << 2;
+    const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fz), 0, f_bytes, 0x00020000);
+    const uint32_t rec_bytes = WIDE ? 0xffffffe0u : static_cast<uint32_t>(a.n_entries) << 5;
+    const __amdgpu_buffer_rsrc_t rec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
+
+    // one drain step: NB * 64 pairs from the front of the ring, NB per lane in flight together
+    // (ring read -> table read and record fetch -> arithmetic -> three LDS adds).  A target's
+    // own record passes the filter once: its displacement is exactly zero, so it adds exactly
+    // zero to the sums (with zero softening p3m_accepted returns 0 for r = 0); it is taken out of
+    // the pair count at the end.
+    auto drain = [&](auto nb_tag, int count) {
+        constexpr int NB = decltype(nb_tag)::value;
+        uint2 e[NB];
+        bool valid[NB];
+        double4 s[NB];
+        double2 gxy[NB];
+        double gz[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            valid[u] = u * 64 + lane < count;
+            e[u] = ring[(rp + u * 64 + lane) & (P3M_POOL_CAP - 1)];
+            if (!valid[u]) e[u] = make_uint2(static_cast<unsigned>(lane), static_cast<unsigned>(p));
+            gxy[u] = txy[wave_base + static_cast<int>(e[u].x)];
+            gz[u] = tz[wave_base + static_cast<int>(e[u].x)];
+            if constexpr (WIDE) s[u] = a.rec[static_cast<int>(e[u].y)];
+            else s[u] = load_record_checked(rec_rsrc, valid[u] ? e[u].y << 5 : 0xffffffe0u);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const double dx = s[u].x - gxy[u].x, dy = s[u].y - gxy[u].y, dz = s[u].z - gz[u];
+            const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+            if (valid[u] && !(r2 > k.cutoff_sq)) {   // the reference's cutoff test (src/particles.cpp:326)
+                double cx = 0.0, cy = 0.0, cz = 0.0;
+                p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, cx, cy, cz);
+                const int slot = wave_base + static_cast<int>(e[u].x);
+                __hip_atomic_fetch_add(&tsum[0][slot], cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&tsum[1][slot], cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&tsum[2][slot], cz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ++hits;
+            }
+        }
+        rp += min(count, NB * 64);
+    };
+
+    const int span = 2 * g.R + 1;
+    const int n_rows = span * span;
+    const int row_jump = g.np * (g.np - span + 1);
+    int base = ((pcx - g.R) * g.np + (pcy - g.R)) * g.np + pcz;
+    int round = 0, oy = 0;
+    int j = 0, je = 0;
+    // padding lanes copy the last target: their runs are empty
+    int nj = live ? load_word(a.cell_start, base - g.R) : 0;
+    int nje = live ? load_word(a.cell_start, base + g.R + 1) : 0;
+#pragma unroll 1
+    for (;;) {
+        if (!__any(j < je)) {   // every lane has finished its run: the next row
+            if (round == n_rows) break;
+            j = nj; je = nje;
+            ++round;
+            const bool wrap = oy + 1 == span;
+            base += (round < n_rows) ? (wrap ? row_jump : g.np) : 0;
+            oy = wrap ? 0 : oy + 1;
+            nj = live ? load_word(a.cell_start, base - g.R) : 0;
+            nje = live ? load_word(a.cell_start, base + g.R + 1) : 0;
+        }
+        p3m_vf cx, cy, cz;
+        if constexpr (WIDE) {
+            const int bb = j < je ? j : p;
+            cx = load_fvec(a.fx, bb); cy = load_fvec(a.fy, bb); cz = load_fvec(a.fz, bb);
+        } else {
+            const uint32_t off = j < je ? static_cast<uint32_t>(j) << 2 : 0xfffffff0u;
+            cx = load_fvec_checked(fx_rsrc, off);
+            cy = load_fvec_checked(fy_rsrc, off);
+            cz = load_fvec_checked(fz_rsrc, off);
+        }
+        const p3m_vf dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
+        const p3m_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+#pragma unroll
+        for (int u = 0; u < P3M_TRIP; ++u) {
+            const bool pass = (j + u < je) & !(r2[u] > bound);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            // the survivors of this slot go to consecutive ring entries in lane order
+            const int at = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), static_cast<unsigned>(wp)));
+            uint2* const where = &ring[at & (P3M_POOL_CAP - 1)];
+            const uint2 entry = make_uint2(static_cast<unsigned>(lane), static_cast<unsigned>(j + u));
+            if (pass) *where = entry;
+            wp += __popcll(m);
+        }
+        j += P3M_TRIP;
+        while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, 128);
+    }
+    while (wp - rp > 0) drain(std::integral_constant<int, 1>{}, wp - rp);
+    __builtin_amdgcn_wave_barrier();
+
+    if (live) {
+        const int o = a.entries[p] - a.tgt_begin;
+        a.ax[o] += tsum[0][threadIdx.x];
+        a.ay[o] += tsum[1][threadIdx.x];
+        a.az[o] += tsum[2][threadIdx.x];
+    }
+    if (a.accepted) {
+        // pairs are counted by the lane that evaluated them; every live target met itself once
+        long long h = static_cast<long long>(hits) - (live ? 1 : 0);
+        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        if (lane == 0 && h) atomicAdd(a.accepted, static_cast<unsigned long long>(h));
     }
 }
 

@@ -15,7 +15,7 @@ KERNEL_NONE, KERNEL_DIRECT, KERNEL_DIRECT_WRAP, KERNEL_P3M_CELLS, KERNEL_P3M_ALL
 NOALLOC_MAX_N = 262144                 # NBPP_NOALLOC_MAX_N
 NOALLOC_SCRATCH_BYTES = 48 * 1024 * 1024  # NBPP_NOALLOC_SCRATCH_BYTES
 OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SEARCH_RADIUS, \
-    OPT_NO_EQUAL_MASS_PATH, OPT_DETERMINISTIC, OPT_P3M_LANES_PER_TARGET = 1, 2, 3, 4, 5, 6, 7, 8
+    OPT_NO_EQUAL_MASS_PATH, OPT_DETERMINISTIC, OPT_P3M_LANES_PER_TARGET, OPT_P3M_POOLED_DRAIN = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 EXPORTS = (
     "nbpp_init", "nbpp_shutdown", "nbpp_last_error", "nbpp_set_option", "nbpp_get_stats",
@@ -46,10 +46,10 @@ class Stats(C.Structure):
         (k, C.c_uint64) for k in ("n_sources", "n_targets", "pairs_evaluated",
                                   "pairs_accepted", "pair_launches", "subtiles_total",
                                   "subtiles_wrapped")] + [
-        ("kernel_variant", C.c_int32), ("reserved", C.c_int32)]
+        ("kernel_variant", C.c_int32), ("p3m_pooled", C.c_int32), ("cell_occupancy", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 _DP = C.POINTER(C.c_double)

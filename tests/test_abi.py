@@ -103,7 +103,7 @@ def test_multi_gpu_partition_is_blocks_of_the_padded_layout():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(ffi.Params) == 9 * 8 + 2 * 4
-    assert ctypes.sizeof(ffi.Stats) == 5 * 8 + 7 * 8 + 2 * 4
+    assert ctypes.sizeof(ffi.Stats) == 5 * 8 + 7 * 8 + 2 * 4 + 8
     from oracle.oracle import Params as OrcParams
     assert [f[0] for f in OrcParams._fields_] == [f[0] for f in ffi.Params._fields_]
 

@@ -841,3 +841,38 @@ def test_zero_transition_width_is_accepted(lib, oracle):
     assert lib.stats()["kernel_variant"] == ffi.KERNEL_P3M_CELLS
     assert all(np.all(np.isfinite(g)) for g in got)
     assert normalised_error(got, want) < TOL
+
+
+# --------------------------------------------------------------------------------------
+# P3M cell kernel: survivors pooled per wavefront against every lane draining its own
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,n_side", [("lattice", 48), ("clustered", 40), ("lattice_soft0", 32)])
+def test_p3m_pooled_drain_equals_per_lane_drain(lib, oracle, name, n_side):
+    """k_p3m_pool against k_p3m_cells on the same inputs: the accepted-pair count is an exact
+    integer and must be identical (and equal to the oracle's); the sums differ only in the order
+    of additions."""
+    n = n_side ** 3
+    pos = datasets.clustered(n, sigma=0.05) if name == "clustered" else datasets.jittered_lattice(n_side, jitter=0.9)
+    m = datasets.masses(n, equal=(name != "clustered"))
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    if name == "lattice_soft0":
+        config.SOFTENING_SQUARED = 0.0
+    p = config.pp_params()
+    out = {}
+    try:
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 1)
+        for pooled in (-1, 1):
+            lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, pooled)
+            out[pooled] = gpu_acc(lib, p, pos, m)
+            st = lib.stats()
+            assert st["kernel_variant"] == ffi.KERNEL_P3M_CELLS and st["p3m_pooled"] == (1 if pooled > 0 else 0)
+            out[pooled, "accepted"] = st["pairs_accepted"]
+    finally:
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
+        lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, 0)
+    assert out[1, "accepted"] == out[-1, "accepted"] == oracle.count_within_cutoff(p, *pos)
+    floor = pair_force_scale(p, m, n) * 1e-3
+    assert normalised_error(out[1], out[-1], floor) < 1e-12
+    n_tgt = 4096
+    want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=O.EXACT_CELLS)
+    assert normalised_error([a[:n_tgt] for a in out[1]], want, floor) < TOL
