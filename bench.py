@@ -391,12 +391,13 @@ def main():
         executed = {1: 25.0, 2: 31.0, 5: 15.5}.get(st.get("kernel_variant"))
         # HBM bytes per launch come from the committed rocprofv3 counter passes of this same
         # command (FETCH_SIZE doubled as the gfx950 correction requires, plus WRITE_SIZE)
-        traffic = None
+        traffic = pipe_busy = None
         prof = os.path.join(ROOT, "profiles", "latest_direct128.json" if not use_pm else "latest_p3m.json")
         if os.path.exists(prof) and world == 1 and n_side == (128 if not use_pm else 256):
             d = json.load(open(prof)).get("derived", {})
             if "hbm_fetch_bytes_x2" in d and "hbm_write_bytes" in d:
                 traffic = d["hbm_fetch_bytes_x2"] + d["hbm_write_bytes"]
+            pipe_busy = d.get("fp64_pipe_busy_frac")
         line = {
             "metric": "pair interactions/sec", "value": value, "unit": "Ginter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -412,7 +413,12 @@ def main():
                          "executed_flops_per_interaction": executed,
                          "executed_frac": (achieved * executed / flops / FP64_VECTOR_PEAK_TFLOPS
                                            if executed else None),
-                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC)",
+                         "fp64_pipe_busy_frac": pipe_busy,
+                         "frac_note": "frac counts the 25 (40 for P3M) algorithmic flop of every interaction; "
+                                      "executed_frac counts the fp64 flop the kernel really issues (the pair-once "
+                                      "kernel serves two interactions with one evaluation); fp64_pipe_busy_frac is "
+                                      "the FP64 pipe occupancy from the committed rocprofv3 counter pass",
+                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, committed profile of this command)",
                          "algorithmic_bytes": 56.0 * n, "kernel_ms": kernel_avg_ms,
                          "prepare_ms": float(np.mean(prep_ms)),
                          "subtiles_wrapped_frac": (st.get("subtiles_wrapped", 0) /

@@ -109,6 +109,7 @@ DeviceEngine::~DeviceEngine() {
     for (double* p : dev_)
         if (p) (void)hipFree(p);
     if (gather_) (void)hipFree(gather_);
+    if (phi_stage_) (void)hipFree(phi_stage_);
     for (double* p : gas_)
         if (p) (void)hipFree(p);
     for (double* p : mesh_)
@@ -230,17 +231,35 @@ double DeviceEngine::next_timestep() {
 void DeviceEngine::download_mesh_solve(std::vector<double>& total_rho, std::vector<double>& phi) {
     total_rho.clear();
     phi.clear();
-    if (!mesh_[0]) return;
+    if (cells_ == 0) return;
     hip_check(hipDeviceSynchronize(), "sync");
+    const nbpm_params mp = config_.mesh_params();
+    if (!mesh_[0]) {
+        // Pair force only, no gas: the step itself needs no mesh, but the reference's KDK_step
+        // assigns the density and solves for the potential on every cycle whatever the switches
+        // (src/integrator.cpp:239-240), so its diagnostics always have them.  Here they are
+        // computed when asked for, from the positions the particles have now.
+        int device = 0;
+        hip_check(hipGetDevice(&device), "hipGetDevice");
+        nbpm_check(nbpm_init(device));
+        for (double*& m : mesh_) hip_check(hipMalloc(reinterpret_cast<void**>(&m), sizeof(double) * cells_), "hipMalloc");
+        meshes_on_demand_ = true;
+    }
+    if (meshes_on_demand_) {
+        deposit_density();
+        nbpm_check(nbpm_solve_device(&mp, mesh_[0], mesh_[2], mesh_[3], mesh_[4], main_));
+    }
     total_rho.resize(cells_);
     phi.resize(cells_);
     const double* source = config_.USE_HYDRO ? mesh_[1] : mesh_[0];
-    hip_check(hipMemcpy(total_rho.data(), source, sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
-    // the potential is staged through the dark-matter density mesh, which the next force phase rebuilds
-    const nbpm_params mp = config_.mesh_params();
-    nbpm_check(nbpm_potential_device(&mp, mesh_[0], main_));
     hip_check(hipStreamSynchronize(static_cast<hipStream_t>(main_)), "sync");
-    hip_check(hipMemcpy(phi.data(), mesh_[0], sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
+    hip_check(hipMemcpy(total_rho.data(), source, sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
+    // the potential comes through a buffer of its own: the density meshes stay what they are, so
+    // a second call before the next force phase returns the same two fields
+    if (!phi_stage_) hip_check(hipMalloc(reinterpret_cast<void**>(&phi_stage_), sizeof(double) * cells_), "hipMalloc");
+    nbpm_check(nbpm_potential_device(&mp, phi_stage_, main_));
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(main_)), "sync");
+    hip_check(hipMemcpy(phi.data(), phi_stage_, sizeof(double) * cells_, hipMemcpyDeviceToHost), "download");
 }
 
 void DeviceEngine::step() {

@@ -44,8 +44,11 @@ class DeviceEngine {
     // blocking copy of the nine gas meshes (density, momentum x/y/z, energy, pressure,
     // velocity x/y/z; MESH_SIZE^3 each); empty without USE_HYDRO
     void download_gas(std::vector<double> (&out)[9]);
-    // blocking copy of the source and the (unnormalised) potential of the last mesh solve, the
-    // reference's state.total_rho and state.phi; empty when no mesh solve has run
+    // blocking copy of the source and the (unnormalised) potential of the mesh solve, the
+    // reference's state.total_rho and state.phi.  When the step itself uses no mesh (pair force
+    // only, no gas) they are computed here, from the current positions, as the reference computes
+    // them on every cycle whatever the switches (src/integrator.cpp:239-240).  Collective with
+    // several ranks.
     void download_mesh_solve(std::vector<double>& total_rho, std::vector<double>& phi);
     double cfl_timestep();               // src/gas.cpp:301-323; +inf without USE_HYDRO
     double gravity_timestep() const;     // src/particles.cpp:386-391
@@ -84,6 +87,9 @@ class DeviceEngine {
     int ranks_ = 0;                      // 0: libnbmg not in use; else the number of processes
     double* dev_[10] = {};               // x y z vx vy vz ax ay az (own block) and m (ALL particles)
     double* gather_ = nullptr;           // several ranks: one padded all-particle array for download()
+    double* phi_stage_ = nullptr;        // download_mesh_solve: the potential on its way to the host
+    bool meshes_on_demand_ = false;      // no mesh in the step (pair force only, no gas): density and
+                                         // potential are computed when download_mesh_solve asks
     double* gas_[9] = {};                // GasGrid's meshes, in nbgas_state order
     double* mesh_[5] = {};               // dm density, total density, gravity x y z
     bool stop_requested_ = false;

@@ -18,8 +18,10 @@ Simulation::Simulation(const Config& config, const RunOptions& options) : config
     ParticleSystem dm = initialize_particles(config_, cosmo, &field);
     engine_.reset(new DeviceEngine(config_, dm, config_.USE_HYDRO ? &field : nullptr));
     engine_->overlap_forces = options_.overlap_forces;
-    engine_->timing_every = options_.timing_every >= 0
-                                ? options_.timing_every
+    // device times are for the log: none are taken when nothing is logged
+    engine_->timing_every = options_.timing_every >= 0 ? options_.timing_every
+                            : config_.DEBUG_INFO_EVERY_CYCLES <= 0
+                                ? 0
                                 : std::max(1, std::min(config_.DEBUG_INFO_EVERY_CYCLES, config_.MAX_CYCLES));
     if (writer_rank() && !options_.snapshot_target.empty() && std::filesystem::is_directory(options_.snapshot_target))
         hdf5_.reset(new SnapshotWriter(options_.snapshot_target, config_));

@@ -15,6 +15,7 @@ using hid = std::int64_t;
 using herr = int;
 using hsize = unsigned long long;
 constexpr unsigned ACC_TRUNC = 0x0002u;   // H5F_ACC_TRUNC
+constexpr unsigned ACC_SWMR_WRITE = 0x0020u;   // H5F_ACC_SWMR_WRITE
 constexpr hid DEFAULT = 0;                // H5P_DEFAULT, H5S_ALL
 constexpr int CLASS_SCALAR = 0;           // H5S_SCALAR
 
@@ -113,9 +114,11 @@ void SnapshotWriter::save_snapshot(int snapshot_index, long /*cycle_count*/, con
                                    const Config& config) {
     const Api& h = *api_;
     const std::string file = path_of(snapshot_index);
-    // The reference adds H5F_ACC_SWMR_WRITE (:64), which only selects the newest file format;
-    // the default format holds the same objects and is read by older tools too.
-    const hid f = h.fcreate(file.c_str(), ACC_TRUNC, DEFAULT, DEFAULT);
+    // Single-writer / multiple-reader access, as the reference opens its files (:64): a viewer may
+    // poll the directory and read a snapshot while the run is still writing.  A library that
+    // refuses the flag (before 1.10) gets the plain file.
+    hid f = h.fcreate(file.c_str(), ACC_TRUNC | ACC_SWMR_WRITE, DEFAULT, DEFAULT);
+    if (f < 0) f = h.fcreate(file.c_str(), ACC_TRUNC, DEFAULT, DEFAULT);
     check(f, "H5Fcreate", file);
     const hid scalar = h.screate(CLASS_SCALAR);
     check(scalar, "H5Screate", file);

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p "$out"
 run() {  # name, rocprof args...
   local name=$1; shift
-  timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --no-cpu-baseline "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
+  timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --no-cpu-baseline --no-extras "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
   tail -1 "$out/$name.log" | cut -c1-300
 }
 BENCH_ARGS=("$@")

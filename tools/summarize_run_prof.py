@@ -1,6 +1,6 @@
 import csv, sys, glob
 log, statsglob, out = sys.argv[1], sys.argv[2], sys.argv[3]
-rows = list(csv.DictReader(open(glob.glob(statsglob)[0])))
+rows = list(csv.DictReader(open(glob.glob(statsglob, recursive=True)[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(out, "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- nbody_amd/host/nbody_host_tests run tools/configs/p3m_hydro_128.ini 100\n\n")
