@@ -127,7 +127,11 @@ def extra_p3m256(lib, ffi, torch, dev, stream, steps=6, warmup=2):
     return {"workload": "P3M short range, 256^3 particles, mesh 256, cutoff 2.5 cells (BASELINE config 3)",
             "value": accepted * steps / elapsed / 1e9, "unit": "G accepted pairs/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
-            "pairs_accepted": accepted, "kernel": "k_p3m_cells", "kernel_ms": k_ms,
+            "pairs_accepted": accepted,
+            "kernel": {0: "k_p3m_cells (every ordered pair, one lane per target)",
+                       1: "k_p3m_pool (survivors pooled per wavefront)",
+                       2: "k_p3m_sym (every unordered pair once, reactions gathered per brick in LDS)"}[st["p3m_pooled"]],
+            "kernel_ms": k_ms,
             "prepare_ms": float(np.mean(prep_ms)),
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
@@ -187,6 +191,10 @@ def main():
     ap.add_argument("--force-kernel", type=int, default=0)
     ap.add_argument("--p3m-radius", type=int, default=0)
     ap.add_argument("--p3m-lanes", type=int, default=0, help="P3M cell kernel: lanes per target (0 = automatic)")
+    ap.add_argument("--p3m-pair-once", type=int, default=0,
+                    help="P3M cell kernel: 1 = every unordered pair once whenever it fits, -1 = never (0 = automatic)")
+    ap.add_argument("--p3m-pooled", type=int, default=0,
+                    help="P3M cell kernel: 1 = survivors pooled per wavefront, -1 = never (0 = automatic)")
     ap.add_argument("--with-mesh", action="store_true",
                     help="p3m mode, one GPU: a step is the whole force phase, mesh force "
                          "(libnbpm) then short range accumulated onto it")
@@ -233,6 +241,8 @@ def main():
     lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, args.p3m_radius)
     lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, args.p3m_lanes)
     lib.set_option(ffi.OPT_DETERMINISTIC, 1 if args.ordered else 0)
+    lib.set_option(ffi.OPT_P3M_PAIR_ONCE, args.p3m_pair_once)
+    lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, args.p3m_pooled)
 
     n_side = args.n_side or (256 if args.mode == "p3m" else 128)
     n = n_side ** 3
@@ -382,7 +392,8 @@ def main():
         pair_shares = use_pairs if mg is None else bool(mg.stats()["pair_shares"])
         my_pairs = pairs_per_step / world if pair_shares else pairs_per_step * (counts[0] / n)
         kernel_names = {1: "k_pairs (ordered pairs)", 2: "k_pairs (per-pair wrap)",
-                        3: "k_p3m_cells", 4: "k_pairs (P3M, all pairs)",
+                        3: ["k_p3m_cells", "k_p3m_pool", "k_p3m_sym"][st.get("p3m_pooled", 0)],
+                        4: "k_pairs (P3M, all pairs)",
                         5: "k_pairs_sym (each unordered pair once, both directions)"}
         achieved = my_pairs * flops / (kernel_avg_ms * 1e-3) / 1e12
         # fp64 flops the kernel really issues per ordered interaction (FMA = 2, rsqrt = 1):

@@ -79,9 +79,10 @@ typedef struct nbpp_stats {
                                 sub-tile) visits ...                                   */
     uint64_t subtiles_wrapped; /* ... and how many needed the per-pair minimum image   */
     int32_t  kernel_variant; /* which pair kernel ran (NBPP_KERNEL_*)                 */
-    int32_t  p3m_pooled;     /* NBPP_KERNEL_P3M_CELLS: 1 if the survivors of the cutoff
-                                pre-filter were pooled per wavefront (see
-                                NBPP_OPT_P3M_POOLED_DRAIN), 0 if each lane drained its own   */
+    int32_t  p3m_pooled;     /* NBPP_KERNEL_P3M_CELLS: 0 if each lane evaluated its own
+                                survivors of the cutoff pre-filter, 1 if they were pooled per
+                                wavefront (NBPP_OPT_P3M_POOLED_DRAIN), 2 if every unordered
+                                pair was evaluated once (NBPP_OPT_P3M_PAIR_ONCE)             */
     double   cell_occupancy; /* NBPP_KERNEL_P3M_CELLS: mean over particles of the number of
                                 particles in the particle's own search cell (1 + the mean
                                 per cell when evenly spread; grows with clustering)          */
@@ -113,11 +114,18 @@ enum {
                                     results are then bitwise reproducible from run to run */
     NBPP_OPT_P3M_LANES_PER_TARGET = 8, /* P3M cell kernel: 0 = automatic (more lanes the fewer
                                     targets), else 1, 2, 4, 8 or 16                       */
-    NBPP_OPT_P3M_POOLED_DRAIN = 9 /* P3M cell kernel with one lane per target: 0 = automatic (pool
+    NBPP_OPT_P3M_POOLED_DRAIN = 9, /* P3M cell kernel with one lane per target: 0 = automatic (pool
                                     the pre-filter's survivors per wavefront and evaluate them 64
                                     at a time, sums added with LDS fp64 atomics, unless
                                     NBPP_OPT_DETERMINISTIC is set), 1 = always, -1 = never (every
                                     lane evaluates its own survivors, bitwise reproducible)  */
+    NBPP_OPT_P3M_PAIR_ONCE = 10  /* P3M cell kernel, all particles as targets: 0 = automatic
+                                    (evaluate every unordered pair once and apply it to both
+                                    members, reactions gathered per brick of cells in LDS and
+                                    added to the outputs with fp64 atomics, when the particle
+                                    set is even enough for a brick's neighbourhood to fit in
+                                    LDS and NBPP_OPT_DETERMINISTIC is off), 1 = whenever it
+                                    fits, -1 = never                                          */
 };
 
 /*

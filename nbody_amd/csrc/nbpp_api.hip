@@ -139,7 +139,7 @@ struct Ctx : Work {
     double* bounce = nullptr;         // page-locked host buffer the sums of nbpp_accumulate come back through
     size_t bounce_bytes = 0;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0;
+            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0;
     nbpp_stats stats{};
 };
 
@@ -516,17 +516,25 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // which decides how many lanes share a target and whether the filter's survivors are pooled
     int n_entries = 0;
     double occupancy = 1.0;
+    // bricks of the pair-once kernel (k_p3m_sym) and the fullest brick's region
+    const int nbx = cdiv(nside, SYM_BX), nby = cdiv(nside, SYM_BY), nbz = cdiv(nside, SYM_BZ);
+    unsigned long long region_max = ~0ull;
     {
-        CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
+        CHK(g.counter.ensure(4 * sizeof(unsigned long long)));
         unsigned long long* occ = g.counter.as<unsigned long long>();
-        HIPCHK(hipMemsetAsync(occ, 0, sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(occ, 0, 4 * sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_occupancy, dim3(static_cast<int>(std::min<long long>(256, cdiv(ncell, WG)))), dim3(WG), 0, s,
                            static_cast<int>(ncell), count, start, occ);
+        const bool sym_possible = all_targets && R <= SYM_MAXR && g.opt_p3m_sym >= 0;
+        if (sym_possible)
+            hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(1LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
+                               nbx, nby, nbz, occ + 2);
         unsigned long long* host = static_cast<unsigned long long*>(g.pinned);
-        HIPCHK(hipMemcpyAsync(host, occ, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(host, occ, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         n_entries = static_cast<int>(host[1]);
         if (n_entries > 0) occupancy = static_cast<double>(host[0]) / n_entries;
+        if (sym_possible) region_max = host[2];
         g.stats.cell_occupancy = occupancy;
     }
     if (n_entries < (grid.keep_len == nside ? n_src : n_tgt))
@@ -614,6 +622,27 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         lanes = static_cast<int>(g.opt_p3m_lanes);
     const dim3 grid_dim(cdiv(static_cast<long long>(n_tgt) * lanes, WG)), wg_dim(WG);
     const bool soft0 = p->soft_sq == 0.0;
+    // every unordered pair once, reactions gathered per brick in LDS (k_p3m_sym): a full
+    // evaluation whose fullest brick region fits, sums not asked to be reproducible, outputs in
+    // ordinary device memory (fp64 atomics).  Chosen by itself for large, even sets (one lane per
+    // target, occupancy measure below the pooled kernel's threshold): measured against
+    // k_p3m_cells on jittered lattices, pair kernel alone, 0.125 / 0.131 ms at 64^3,
+    // 0.673 / 0.711 at 128^3, 2.05 / 2.30 at 192^3, 4.67 / 5.00 at 256^3.
+    const bool sym = all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide &&
+                     n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
+                     (g.opt_p3m_sym > 0 ||
+                      (g.opt_p3m_sym == 0 && !g.opt_deterministic && lanes == 1 && occupancy < 6.0));
+    g.stats.p3m_pooled = 0;
+    if (sym) {
+        const dim3 bricks(nbx * nby * nbz);
+        if (soft0) hipLaunchKernelGGL((k_p3m_sym<true>), bricks, dim3(SYM_WG), 0, s, a, nbx, nby, nbz);
+        else hipLaunchKernelGGL((k_p3m_sym<false>), bricks, dim3(SYM_WG), 0, s, a, nbx, nby, nbz);
+        HIPCHK(hipGetLastError());
+        g.stats.p3m_pooled = 2;
+        g.stats.pairs_evaluated = 0;
+        g.stats.pair_launches = 1;
+        return NBPP_OK;
+    }
     // one lane per target on a clustered set: the survivors of the filter are pooled per
     // wavefront and evaluated 64 at a time whatever target they belong to (k_p3m_pool), unless
     // reproducible sums are asked for.  Measured, kernel time pooled against per lane: 256^3
@@ -795,6 +824,7 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_DETERMINISTIC: g.opt_deterministic = value; return NBPP_OK;
         case NBPP_OPT_P3M_LANES_PER_TARGET: g.opt_p3m_lanes = value; return NBPP_OK;
         case NBPP_OPT_P3M_POOLED_DRAIN: g.opt_p3m_pooled = value; return NBPP_OK;
+        case NBPP_OPT_P3M_PAIR_ONCE: g.opt_p3m_sym = value; return NBPP_OK;
         default: return fail(NBPP_ERR_ARG, "unknown option key %d", key);
     }
 }

@@ -1046,7 +1046,7 @@ __device__ __forceinline__ int load_word(const int* base, int idx) {   // idx < 
     return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) +
                                          (static_cast<uint32_t>(idx) << 2));
 }
-static_assert((P3M_QCAP & (P3M_QCAP - 1)) == 0 && P3M_DRAIN % P3M_DRAIN_UNROLL == 0 &&
+static_assert((P3M_QCAP & (P3M_QCAP - 1)) == 0 && P3M_DRAIN % P3M_DRAIN_UNROLL == 0 && P3M_DRAIN % 4 == 0 &&
               P3M_QCAP % P3M_DRAIN_UNROLL == 0 && P3M_DRAIN >= P3M_TRIP && (P3M_TRIP == 2 || P3M_TRIP == 4 || P3M_TRIP == 8),
               "ring sizes");
 __device__ __forceinline__ int ring_slot(int i) { return i & (P3M_QCAP - 1); }
@@ -1234,10 +1234,11 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
             const p3m_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
             // the slot after the newest entry is free (at most QCAP - P3M_TRIP queued on entry):
             // the stores need no branch
+            const int left = je - j;          // candidates of this trip that belong to the run
 #pragma unroll
             for (int u = 0; u < P3M_TRIP; ++u) {
                 queue[ring_slot(wp)][threadIdx.x] = j + u;
-                wp += ((j + u < je) & !(r2[u] > bound)) ? 1 : 0;
+                wp += ((u < left) & !(r2[u] > bound)) ? 1 : 0;
             }
             j += P3M_TRIP;
             if (__any(wp > lim)) break;
@@ -1423,6 +1424,350 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
         long long h = static_cast<long long>(hits) - (live ? 1 : 0);
         for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
         if (lane == 0 && h) atomicAdd(a.accepted, static_cast<unsigned long long>(h));
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Every unordered pair once (Newton's third law) for the P3M short range.
+//
+// The reference evaluates (i, j) and (j, i) separately (src/particles.cpp:270-365); their
+// displacements are exact negatives and the scalar factor S (f_pp - f_pm) is the same, so one
+// evaluation serves both: a_i += G m_j f d, a_j -= G m_i f d.  That halves the candidates a
+// target has to test as well as the accepted pairs it has to evaluate: a target only looks
+// FORWARD, at the rows (ox, oy) of its neighbourhood that follow its own in (x, y) order and at
+// the entries behind itself in its own row.  With ghost images every unordered pair of particles
+// is then met by exactly one of its two members (the image of a forward offset is a backward one).
+//
+// The reaction a_j has to be added to a particle another lane, wavefront or workgroup may be
+// adding to as well.  A workgroup therefore owns a BRICK of SYM_BX x SYM_BY x SYM_BZ search
+// cells: its targets are the brick's real entries, and every source they can meet lies in the
+// region [x0, x0 + BX + R) x [y0 - R, y0 + BY + R) x [z0 - R, z0 + BZ + R), a few dozen columns
+// whose z segments are contiguous runs of the sorted records.  One fp64 sum triple per region
+// entry lives in LDS; lanes add reactions there with ds_add_f64, a target adds its own sums to
+// its own entry at the end, and when the brick is done every non-zero triple is added to the
+// output with global fp64 atomics, once per region entry instead of once per pair (about 11
+// atomics per target instead of 107).  Not bitwise reproducible; ordinary device memory only.
+// ---------------------------------------------------------------------------------
+constexpr int SYM_WG = 512;         // 8 wavefronts per brick; two bricks share a CU's LDS, so one's set-up and
+                                    // flush run beside the other's pair loop
+constexpr int SYM_BX = 4, SYM_BY = 4, SYM_BZ = 14;   // ~440 targets at two particles per search cell
+constexpr int SYM_CAP = 1920;       // region entries whose sums fit in LDS (45 KiB)
+constexpr bool SYM_PREFETCH = false;   // request trip i + 1's coordinates before trip i is tested: 24 more
+                                       // registers, which four record fetches per drain step use better
+                                       // (256^3: 4.67 ms against 4.81 with the prefetch and two fetches)
+constexpr int SYM_DU = 4;           // record fetches in flight per lane while draining
+constexpr int SYM_MAXR = 3;         // search radius in cells the tables are sized for
+constexpr int SYM_MAXCOL = (SYM_BX + SYM_MAXR) * (SYM_BY + 2 * SYM_MAXR);
+constexpr int SYM_JBITS = 25;       // ring entries: region column << 25 | sorted position
+
+// S (f_pp - f_pm) of src/particles.cpp:330-355 for r^2 <= cutoff_sq (without G m and d).
+template <bool SOFT0>
+__device__ __forceinline__ double p3m_factor(double r2, const PairConsts& k) {
+    auto cube = [&](double q) {
+        const double y = __builtin_amdgcn_rsq(q);
+        const double y2 = y * y;
+        const double h = __builtin_fma(-q, y2, 1.0);
+        const double y3 = y * y2;
+        return __builtin_fma(y3, h * __builtin_fma(k.c1875, h, k.c15), y3);
+    };
+    const double q1 = r2 + k.eps2;
+    double f1 = cube(q1);
+    if constexpr (SOFT0) f1 = (q1 > 0.0) ? f1 : 0.0;
+    double f = f1 - cube(r2 + k.eps_pm2);
+    if (r2 > k.r_switch_sq) {
+        const double dist = r2 * inv_sqrt_refined(r2);
+        const double t = (dist - k.r_switch) * k.inv_width;
+        f *= __builtin_fma(t * t, __builtin_fma(2.0, t, -3.0), 1.0);
+    }
+    return f;
+}
+
+// Largest number of region entries over all bricks: the launch falls back to k_p3m_cells when
+// one does not fit SYM_CAP (a clustered set).
+__global__ void k_sym_region_max(GhostGrid g, const int* __restrict__ cell_start, int nbx, int nby, int nbz,
+                                 unsigned long long* __restrict__ out) {
+    const int brick = blockIdx.x * blockDim.x + threadIdx.x;
+    if (brick >= nbx * nby * nbz) return;
+    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+    const int x0 = g.R + bx * SYM_BX, y0 = g.R + by * SYM_BY, z0 = g.R + bz * SYM_BZ;
+    const int zlo = z0 - g.R, zhi = min(z0 + SYM_BZ, g.R + g.nside) + g.R;
+    int total = 0;
+    for (int rx = 0; rx < SYM_BX + g.R; ++rx)
+        for (int ry = 0; ry < SYM_BY + 2 * g.R; ++ry) {
+            const int px = x0 + rx, py = y0 - g.R + ry;
+            if (px >= g.np || py >= g.np) continue;
+            const int col = (px * g.np + py) * g.np;
+            total += cell_start[col + zhi] - cell_start[col + zlo];
+        }
+    atomicMax(out, static_cast<unsigned long long>(total));
+}
+
+template <bool SOFT0>
+__global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx, int nby, int nbz) {
+    __shared__ double acc[3][SYM_CAP];
+    __shared__ int queue[P3M_QCAP][SYM_WG];
+    __shared__ int col_off[SYM_MAXCOL + 1];    // first LDS entry of every region column
+    __shared__ int col_delta[SYM_MAXCOL];      // LDS entry = sorted position + col_delta[column]
+    __shared__ int piece_off[SYM_BX * SYM_BY + 1], piece_start[SYM_BX * SYM_BY];   // the brick's targets, column by column
+    const GhostGrid g = a.g;
+    const PairConsts k = a.k;
+    const int b = static_cast<int>(blockIdx.x);      // XCD-aware order of the bricks: see k_p3m_cells
+    const int group = b / (8 * P3M_XCD_RUN);
+    const int in_group = b - group * (8 * P3M_XCD_RUN);
+    const bool whole = (group + 1) * (8 * P3M_XCD_RUN) <= static_cast<int>(gridDim.x);
+    const int brick = whole ? group * (8 * P3M_XCD_RUN) + (in_group % 8) * P3M_XCD_RUN + in_group / 8 : b;
+    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+    const int x0 = g.R + bx * SYM_BX, y0 = g.R + by * SYM_BY, z0 = g.R + bz * SYM_BZ;
+    const int z1 = min(z0 + SYM_BZ, g.R + g.nside);       // the brick's real cells end here
+    const int CY = SYM_BY + 2 * g.R, ncols = (SYM_BX + g.R) * CY;
+    const int tid = threadIdx.x;
+
+    // ---- the region's columns and the brick's target pieces
+    if (tid < ncols) {
+        const int rx = tid / CY, ry = tid - rx * CY;
+        const int px = x0 + rx, py = y0 - g.R + ry;
+        int first = 0, count = 0;
+        if (px < g.np && py < g.np) {
+            const int col = (px * g.np + py) * g.np;
+            first = a.cell_start[col + z0 - g.R];
+            count = a.cell_start[col + z1 + g.R] - first;
+        }
+        col_delta[tid] = first;      // for now: the column's first sorted position
+        col_off[tid + 1] = count;    // for now: its length
+    }
+    if (tid < SYM_BX * SYM_BY) {
+        const int rx = tid / SYM_BY, ry = tid - rx * SYM_BY;
+        const int px = x0 + rx, py = y0 + ry;
+        int first = 0, count = 0;
+        if (px < g.R + g.nside && py < g.R + g.nside) {
+            const int col = (px * g.np + py) * g.np;
+            first = a.cell_start[col + z0];
+            count = a.cell_start[col + z1] - first;
+        }
+        piece_start[tid] = first;
+        piece_off[tid + 1] = count;
+    }
+    __syncthreads();
+    if (tid < 64) {               // first wavefront: running sums of the column lengths, 64 columns at a time
+        int carry = 0;
+        for (int c0 = 0; c0 < ncols; c0 += 64) {
+            const int c = c0 + tid;
+            const int count = c < ncols ? col_off[c + 1] : 0;
+            int incl = count;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                incl += tid >= d ? up : 0;
+            }
+            if (c < ncols) {
+                col_delta[c] = carry + incl - count - col_delta[c];
+                col_off[c + 1] = carry + incl;
+            }
+            carry += __shfl(incl, 63, 64);
+        }
+        if (tid == 0) col_off[0] = 0;
+    } else if (tid < 128) {       // second wavefront: the same for the target pieces
+        const int l = tid - 64;
+        const int count = l < SYM_BX * SYM_BY ? piece_off[l + 1] : 0;
+        int incl = count;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            incl += l >= d ? up : 0;
+        }
+        if (l < SYM_BX * SYM_BY) piece_off[l + 1] = incl;
+        if (l == 0) piece_off[0] = 0;
+    }
+    __syncthreads();
+    const int n_region = col_off[ncols];
+    const int n_mine = piece_off[SYM_BX * SYM_BY];
+    for (int e = tid; e < n_region; e += SYM_WG) {
+        acc[0][e] = 0.0;
+        acc[1][e] = 0.0;
+        acc[2][e] = 0.0;
+    }
+    __syncthreads();
+
+    const float bound = a.prefilter_sq;
+    const uint32_t f_bytes = static_cast<uint32_t>(a.n_entries + P3M_TRIP) << 2;
+    const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fz), 0, f_bytes, 0x00020000);
+    const uint32_t rec_bytes = static_cast<uint32_t>(a.n_entries) << 5;
+    const __amdgpu_buffer_rsrc_t rec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
+    const int span = 2 * g.R + 1;
+    const int n_rows = g.R * span + g.R + 1;     // the own row, then every row after it in (x, y) order
+    unsigned hits = 0;
+    constexpr int DU = SYM_DU;
+
+#pragma unroll 1
+    for (int chunk = 0; chunk * SYM_WG < n_mine; ++chunk) {
+        const int t = chunk * SYM_WG + tid;
+        const bool live = t < n_mine;
+        if (!__any(live)) continue;          // a wavefront without targets in this chunk
+        int piece = 0;
+#pragma unroll
+        for (int c = 1; c < SYM_BX * SYM_BY; ++c) piece += (live && t >= piece_off[c]) ? 1 : 0;
+        const int p = live ? piece_start[piece] + (t - piece_off[piece]) : 0;
+        const double4 me = a.rec[p];
+        const p3m_vf nmx = -a.fx[p], nmy = -a.fy[p], nmz = -a.fz[p];
+        const int rcx = piece / SYM_BY, rcy = piece - rcx * SYM_BY + g.R;   // own column inside the region
+        const int pcx = x0 + rcx, pcy = y0 + rcy - g.R;
+        const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
+        double ax = 0.0, ay = 0.0, az = 0.0;
+        int rp = 0, wp = 0;
+        int lim = P3M_QCAP - P3M_TRIP;
+
+        auto drain = [&](int quota) {
+            const int cnt = wp - rp;
+#pragma unroll 1
+            for (int q = 0; q < quota && __any(q < cnt); q += DU) {
+                double4 s[DU];
+                bool valid[DU];
+                int slot[DU];
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    valid[u] = q + u < cnt;
+                    const unsigned e = valid[u] ? static_cast<unsigned>(queue[ring_slot(rp + q + u)][tid]) : 0u;
+                    const unsigned jj = e & ((1u << SYM_JBITS) - 1u);
+                    slot[u] = static_cast<int>(jj) + col_delta[e >> SYM_JBITS];
+                    s[u] = load_record_checked(rec_rsrc, valid[u] ? jj << 5 : 0xffffffe0u);
+                }
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    const double dx = s[u].x - me.x, dy = s[u].y - me.y, dz = s[u].z - me.z;
+                    const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+                    if (valid[u] && !(r2 > k.cutoff_sq)) {     // src/particles.cpp:326
+                        const double f = p3m_factor<SOFT0>(r2, k);
+                        const double fx = f * dx, fy = f * dy, fz = f * dz;
+                        ax = __builtin_fma(s[u].w, fx, ax);    // a_i += G m_j f d
+                        ay = __builtin_fma(s[u].w, fy, ay);
+                        az = __builtin_fma(s[u].w, fz, az);
+                        const double ngm = -me.w;              // a_j -= G m_i f d
+                        __hip_atomic_fetch_add(&acc[0][slot[u]], ngm * fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&acc[1][slot[u]], ngm * fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&acc[2][slot[u]], ngm * fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ++hits;
+                    }
+                }
+            }
+            rp += min(quota, cnt);
+            lim = rp + (P3M_QCAP - P3M_TRIP);
+        };
+
+        // row r: 0 the own row (entries behind p only), 1..R the rows (0, 1..R), then (1..R, -R..R);
+        // called with r = 0, 1, 2, ...: (ox, oy) step along
+        int ox = 0, oy = -1;
+        auto row_bounds = [&](int r, int& first, int& last, int& tg) {
+            ++oy;
+            if (oy > g.R) { oy = -g.R; ++ox; }
+            const bool has = live && r < n_rows;
+            const int base = ((pcx + ox) * g.np + (pcy + oy)) * g.np + pcz;
+            first = has ? load_word(a.cell_start, base - g.R) : 0;
+            last = has ? load_word(a.cell_start, base + g.R + 1) : 0;
+            if (r == 0) first = has ? p + 1 : 0;
+            tg = ((rcx + ox) * CY + (rcy + oy)) << SYM_JBITS;
+        };
+        int round = 0;
+        int j = 0, je = 0, tag = 0;
+        int nj, nje, ntag;
+        row_bounds(0, nj, nje, ntag);
+        // moves (j, je, tag) to the next trip of P3M_TRIP candidates; false once the rows are used up
+        auto next_trip = [&]() -> bool {
+            j += P3M_TRIP;
+            if (!__any(j < je)) {
+                if (round == n_rows) return false;
+                j = nj; je = nje; tag = ntag;
+                ++round;
+                row_bounds(round, nj, nje, ntag);
+            }
+            return true;
+        };
+        auto fetch = [&](p3m_vf& vx, p3m_vf& vy, p3m_vf& vz) {
+            const uint32_t off = j < je ? static_cast<uint32_t>(j) << 2 : 0xfffffff0u;
+            vx = load_fvec_checked(fx_rsrc, off);
+            vy = load_fvec_checked(fy_rsrc, off);
+            vz = load_fvec_checked(fz_rsrc, off);
+        };
+        // the coordinates of trip i + 1 are requested before trip i is tested and queued, so that
+        // their latency runs beside that work (only four wavefronts share a SIMD here); two
+        // register sets take turns, so nothing is copied
+        auto test_and_queue = [&](const p3m_vf& cx, const p3m_vf& cy, const p3m_vf& cz, int cj, int cje, int ctag) {
+            const p3m_vf dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
+            const p3m_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+            const int left = cje - cj;          // candidates of this trip that belong to the run
+            const int first = ctag | cj;
+#pragma unroll
+            for (int u = 0; u < P3M_TRIP; ++u) {
+                queue[ring_slot(wp)][tid] = first + u;
+                wp += ((u < left) & !(r2[u] > bound)) ? 1 : 0;
+            }
+            if (__any(wp > lim)) drain(P3M_DRAIN);
+        };
+        p3m_vf ax0 = 0.0f, ay0 = 0.0f, az0 = 0.0f, ax1 = 0.0f, ay1 = 0.0f, az1 = 0.0f;
+        bool more = next_trip();
+        if constexpr (!SYM_PREFETCH) {
+#pragma unroll 1
+            while (more) {
+                fetch(ax0, ay0, az0);
+                test_and_queue(ax0, ay0, az0, j, je, tag);
+                more = next_trip();
+            }
+        }
+        if (more) fetch(ax0, ay0, az0);
+#pragma unroll 1
+        while (more) {
+            int cj = j, cje = je, ctag = tag;
+            more = next_trip();
+            if (more) fetch(ax1, ay1, az1);
+            test_and_queue(ax0, ay0, az0, cj, cje, ctag);
+            if (!more) break;
+            cj = j; cje = je; ctag = tag;
+            more = next_trip();
+            if (more) fetch(ax0, ay0, az0);
+            test_and_queue(ax1, ay1, az1, cj, cje, ctag);
+        }
+        while (__any(wp > rp)) drain(P3M_QCAP);
+        if (live) {   // the target's own sums join what others add to it
+            const int own = p + col_delta[rcx * CY + rcy];
+            __hip_atomic_fetch_add(&acc[0][own], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&acc[1][own], ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&acc[2][own], az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+
+    // ---- every region entry that received something goes out once (FL entries per lane in
+    // flight: the look-up of the particle's index is a dependent global load)
+    constexpr int FL = 4;
+    for (int e0 = tid; e0 < n_region; e0 += FL * SYM_WG) {
+        int o[FL];
+        bool any[FL];
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int e = e0 + u * SYM_WG;
+            any[u] = e < n_region && (acc[0][e] != 0.0 || acc[1][e] != 0.0 || acc[2][e] != 0.0);
+            int lo = 0, hi = ncols;                  // column of entry e: col_off[lo] <= e < col_off[lo + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (col_off[mid] <= e) lo = mid; else hi = mid;
+            }
+            o[u] = any[u] ? a.entries[e - col_delta[lo]] - a.tgt_begin : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            if (!any[u]) continue;
+            const int e = e0 + u * SYM_WG;
+            unsafeAtomicAdd(&a.ax[o[u]], acc[0][e]);
+            unsafeAtomicAdd(&a.ay[o[u]], acc[1][e]);
+            unsafeAtomicAdd(&a.az[o[u]], acc[2][e]);
+        }
+    }
+    if (a.accepted) {
+        unsigned long long h = 2ull * hits;          // both members of every pair
+        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        if ((tid & 63) == 0 && h) atomicAdd(a.accepted, h);
     }
 }
 

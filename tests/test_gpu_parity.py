@@ -861,6 +861,7 @@ def test_p3m_pooled_drain_equals_per_lane_drain(lib, oracle, name, n_side):
     out = {}
     try:
         lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 1)
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, -1)
         for pooled in (-1, 1):
             lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, pooled)
             out[pooled] = gpu_acc(lib, p, pos, m)
@@ -870,9 +871,66 @@ def test_p3m_pooled_drain_equals_per_lane_drain(lib, oracle, name, n_side):
     finally:
         lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
         lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, 0)
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
     assert out[1, "accepted"] == out[-1, "accepted"] == oracle.count_within_cutoff(p, *pos)
     floor = pair_force_scale(p, m, n) * 1e-3
     assert normalised_error(out[1], out[-1], floor) < 1e-12
     n_tgt = 4096
     want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=O.EXACT_CELLS)
     assert normalised_error([a[:n_tgt] for a in out[1]], want, floor) < TOL
+
+
+# --------------------------------------------------------------------------------------
+# P3M cell kernel: every unordered pair once (reactions gathered per brick in LDS)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,n_side,mesh", [("lattice", 48, 48), ("lattice_r2", 64, 64), ("uneven_grid", 37, 41),
+                                              ("lattice_soft0", 32, 32), ("unequal_masses", 40, 40)])
+def test_p3m_pair_once_equals_ordered_pairs(lib, oracle, name, n_side, mesh):
+    """k_p3m_sym against k_p3m_cells on the same inputs: twice the unordered pairs it evaluates
+    must be the ordered-pair count (an exact integer, equal to the oracle's), and the sums must
+    agree to rounding.  Grids that are not a multiple of the brick size, both search radii,
+    zero softening and unequal masses (the reaction carries the target's mass)."""
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side, jitter=0.9)
+    m = datasets.masses(n, equal=(name != "unequal_masses"))
+    config = Config(MESH_SIZE=mesh, N_PER_SIDE=n_side, USE_PM=True)
+    if name == "lattice_soft0":
+        config.SOFTENING_SQUARED = 0.0
+    p = config.pp_params()
+    out = {}
+    try:
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 1)
+        lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, -1)
+        for once in (-1, 1):
+            lib.set_option(ffi.OPT_P3M_PAIR_ONCE, once)
+            out[once] = gpu_acc(lib, p, pos, m, acc0=[np.full(n, 0.5), np.zeros(n), np.full(n, -2.0)])
+            st = lib.stats()
+            assert st["kernel_variant"] == ffi.KERNEL_P3M_CELLS and st["p3m_pooled"] == (2 if once > 0 else 0)
+            out[once, "accepted"] = st["pairs_accepted"]
+    finally:
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
+        lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, 0)
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
+    assert out[1, "accepted"] == out[-1, "accepted"] == oracle.count_within_cutoff(p, *pos)
+    floor = pair_force_scale(p, m, n) * 1e-3
+    start = [0.5, 0.0, -2.0]
+    a = [o - s for o, s in zip(out[1], start)]
+    b = [o - s for o, s in zip(out[-1], start)]
+    assert normalised_error(a, b, floor) < 1e-11
+    n_tgt = 2048
+    want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=O.EXACT_CELLS)
+    assert normalised_error([c[:n_tgt] for c in a], want, floor) < TOL
+
+
+def test_p3m_pair_once_falls_back_on_a_clustered_set(lib):
+    """A brick whose neighbourhood does not fit in LDS: the ordinary kernels take the call."""
+    n = 64 ** 3
+    pos = datasets.clustered(n, n_blobs=3, sigma=0.01)
+    m = datasets.masses(n)
+    p = Config(MESH_SIZE=64, N_PER_SIDE=64, USE_PM=True).pp_params()
+    lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 1)
+    try:
+        gpu_acc(lib, p, pos, m)
+        assert lib.stats()["p3m_pooled"] != 2
+    finally:
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)

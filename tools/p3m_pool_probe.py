@@ -38,8 +38,9 @@ for name, n_side, make in sets:
         torch.full((n,), config.DM_PARTICLE_MASS, dtype=torch.float64, device="cuda:0")]
     acc = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
     lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 1)
-    for pooled in (-1, 1):
-        lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, pooled)
+    for pooled in (-1, 1, 2):
+        lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, 1 if pooled == 1 else -1)
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 1 if pooled == 2 else -1)
         best = None
         for _ in range(4):
             lib.accumulate_device(p, *d, *acc)
@@ -47,13 +48,19 @@ for name, n_side, make in sets:
             st = lib.stats()
             if best is None or st["pair_kernel_ms"] < best["pair_kernel_ms"]:
                 best = st
-        rows.append({"set": name, "pooled": pooled > 0, "kernel_ms": best["pair_kernel_ms"],
+        if pooled == 2 and best["p3m_pooled"] != 2:
+            print(f"{name:28s} pair once: does not fit (fell back)", flush=True)
+            continue
+        rows.append({"set": name, "kernel": {-1: "k_p3m_cells", 1: "k_p3m_pool", 2: "k_p3m_sym"}[pooled],
+                     "kernel_ms": best["pair_kernel_ms"],
                      "pairs_accepted": best["pairs_accepted"], "cell_occupancy": best["cell_occupancy"],
                      "G_pairs_per_s": best["pairs_accepted"] / best["pair_kernel_ms"] * 1e-6})
-        print(f"{name:28s} {'pooled  ' if pooled > 0 else 'per lane'}: kernel {best['pair_kernel_ms']:8.3f} ms, "
+        label = {-1: "per lane ", 1: "pooled   ", 2: "pair once"}[pooled]
+        print(f"{name:28s} {label}: kernel {best['pair_kernel_ms']:8.3f} ms, "
               f"{best['pairs_accepted']:.4g} accepted pairs, {rows[-1]['G_pairs_per_s']:.1f} G/s, "
               f"cell occupancy {best['cell_occupancy']:.2f}", flush=True)
     lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
     lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, 0)
+    lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
 if "--json" in sys.argv:
     json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
