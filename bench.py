@@ -202,6 +202,9 @@ def main():
                     help="several GPUs: 'native' = libnbmg (the library owns the RCCL communicator, "
                          "ncclAllGather / ncclReduceScatter below the C ABI), 'torch' = the same "
                          "collectives issued through torch.distributed")
+    ap.add_argument("--halo-exchange", action="store_true",
+                    help="P3M on several GPUs, native path: send each peer only the particles within a "
+                         "cutoff radius of its block instead of all-gathering every position")
     ap.add_argument("--native-one-rank", action="store_true",
                     help="one GPU: go through libnbmg with a communicator of one rank (exercises the "
                          "multi-GPU code path on a single-GPU box)")
@@ -289,6 +292,7 @@ def main():
             mg.init(rank, world, bytes(ident.cpu().numpy().tobytes()), local_rank)
             mg.set_option(ffi.MG_OPT_TIMING, 1)
             mg.set_option(ffi.MG_OPT_PAIR_SHARES, -1 if args.ordered else 0)
+            mg.set_option(ffi.MG_OPT_HALO_EXCHANGE, 1 if args.halo_exchange else 0)
             ok = 1
         except Exception as e:   # every rank must take the same path: agree below
             comm_note = f"native multi-GPU layer failed to start ({e!r}); torch.distributed collectives used"
@@ -439,13 +443,17 @@ def main():
             if mg is not None:
                 ag, rs, cp = (float(np.mean([c[k] for c in comm_ms])) for k in range(3))
                 st_mg = mg.stats()
+                halo = args.mode == "p3m" and args.halo_exchange and world > 1
                 line["config"]["parallelism"] = (
-                    f"block partition x{world}, libnbmg: ncclAllGather of positions per evaluation, "
+                    f"block partition x{world}, libnbmg: "
+                    + ("halo exchange (ncclSend / ncclRecv of the particles within a cutoff radius of a "
+                       "peer's block), " if halo else "ncclAllGather of positions per evaluation, ")
                     + ("shares of the unordered pairs + ncclReduceScatter" if pair_shares
                        else "own targets against all sources, no reduction"))
                 line["comm"] = {"backend": "RCCL via libnbmg (C ABI)", "allgather_ms": ag, "reduce_scatter_ms": rs,
                                 "compute_ms": cp, "allgather_bytes_per_rank": st_mg["allgather_bytes"],
-                                "reduce_bytes_per_rank": st_mg["reduce_bytes"], "rank": 0}
+                                "reduce_bytes_per_rank": st_mg["reduce_bytes"],
+                                "halo_particles_rank0": st_mg["halo_particles"], "rank": 0}
             else:
                 line["comm"] = {"backend": "gloo (rehearsal)" if rehearsal else "RCCL via torch.distributed",
                                 "note": comm_note}

@@ -53,14 +53,22 @@ typedef struct nbmg_stats {
     int32_t pair_shares;      /* 1: every unordered pair once across the ranks + reduce-scatter;
                                  0: this rank's targets against all sources, no reduction     */
     int32_t reserved;
+    uint64_t halo_particles;  /* halo exchange: particles this rank received from its peers
+                                 (allgather_bytes then counts their 32 bytes each)           */
 } nbmg_stats;
 
 enum {
     NBMG_OPT_TIMING = 1,      /* 1 = record HIP-event times into nbmg_stats (waits for the GPU) */
-    NBMG_OPT_PAIR_SHARES = 2  /* direct summation: 0 = automatic (shares of the unordered pairs on
+    NBMG_OPT_PAIR_SHARES = 2, /* direct summation: 0 = automatic (shares of the unordered pairs on
                                  more than one rank), 1 = always, -1 = never (i-partition,
                                  all-gather only, bitwise reproducible with
                                  NBPP_OPT_DETERMINISTIC)                                        */
+    NBMG_OPT_HALO_EXCHANGE = 3 /* P3M short range on more than one rank: 1 = instead of
+                                 all-gathering every position, each rank sends a peer only its
+                                 particles within a cutoff radius of that peer's block
+                                 (nbmg_x_extent_device, nbmg_halo_select_device, ncclSend /
+                                 ncclRecv); 0 = all-gather (default); 2 = that code path on
+                                 one rank too (nothing travels; for tests)                      */
 };
 
 /*
@@ -71,7 +79,8 @@ enum {
  * nbmg_init_from_env does both for processes started by a launcher that sets RANK, WORLD_SIZE
  * and LOCAL_RANK (torch.distributed.run, mpirun wrappers): rank 0 writes the id to the file named
  * by NBMG_ID_FILE (default /tmp/nbmg_id_<MASTER_PORT>), the others wait for it; without
- * WORLD_SIZE it is nbmg_init(0, 1, NULL, 0).
+ * WORLD_SIZE it is nbmg_init(0, 1, NULL, 0).  NBMG_HALO_EXCHANGE in the environment sets the option
+ * of that name.
  * Replaces: the implicit single device of the reference's `omp target` region
  * (src/particles.cpp:169).
  */
@@ -119,6 +128,24 @@ int nbmg_allreduce_max_device(size_t count, double* data, void* stream);
 int nbmg_accumulate_device(const nbpp_params* p, size_t n,
                            const double* own_x, const double* own_y, const double* own_z,
                            const double* m_full, double* ax, double* ay, double* az, void* stream);
+
+/*
+ * The pieces of the halo exchange (NBMG_OPT_HALO_EXCHANGE), usable on their own; both block until
+ * their result is on the host.
+ * nbmg_x_extent_device: the circular x interval [*lo, *hi] that holds all `count` positions x
+ *     (DEVICE pointer): the complement of the longest empty stretch of the box, to 1/4096 of the
+ *     box; *lo > *hi means the interval wraps through x = 0; [0, L] when there is no gap.
+ * nbmg_halo_select_device: the particles whose x lies within `margin` of the circular interval
+ *     [lo, hi], in index order, packed into `out` (DEVICE, 4 * capacity doubles: x at out[0..),
+ *     y at out[capacity..), z at out[2 capacity..), m at out[3 capacity..)); *n_selected is
+ *     their number.  out == NULL only counts.
+ * No counterpart in the reference (one process, one device boundary, src/particles.cpp:169-173).
+ */
+int nbmg_x_extent_device(size_t count, const double* x, double domain_size, double* lo, double* hi,
+                         void* stream);
+int nbmg_halo_select_device(size_t count, const double* x, const double* y, const double* z,
+                            const double* m, double domain_size, double lo, double hi, double margin,
+                            double* out, size_t capacity, size_t* n_selected, void* stream);
 
 /*
  * max(1e-9, max over ALL ranks' particles of ax^2 + ay^2 + az^2) -> *out_host on every rank

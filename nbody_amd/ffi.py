@@ -473,15 +473,16 @@ MG_EXPORTS = (
     "nbmg_rank", "nbmg_nranks", "nbmg_set_option", "nbmg_get_stats", "nbmg_partition",
     "nbmg_padded_length", "nbmg_allgather_device", "nbmg_allreduce_sum_device",
     "nbmg_allreduce_max_device", "nbmg_accumulate_device", "nbmg_max_accel_sq_device",
+    "nbmg_x_extent_device", "nbmg_halo_select_device",
 )
 MG_UNIQUE_ID_BYTES = 128
-MG_OPT_TIMING, MG_OPT_PAIR_SHARES = 1, 2
+MG_OPT_TIMING, MG_OPT_PAIR_SHARES, MG_OPT_HALO_EXCHANGE = 1, 2, 3
 
 
 class MultiGpuStats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("allgather_ms", "compute_ms", "reduce_ms", "total_ms")] + [
         ("allgather_bytes", C.c_uint64), ("reduce_bytes", C.c_uint64),
-        ("pair_shares", C.c_int32), ("reserved", C.c_int32)]
+        ("pair_shares", C.c_int32), ("reserved", C.c_int32), ("halo_particles", C.c_uint64)]
 
 
 class MultiGpuLibrary:
@@ -514,6 +515,9 @@ class MultiGpuLibrary:
         L.nbmg_allreduce_max_device.argtypes = [C.c_size_t, _DP, C.c_void_p]
         L.nbmg_accumulate_device.argtypes = [C.POINTER(Params), C.c_size_t] + [_DP] * 7 + [C.c_void_p]
         L.nbmg_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
+        L.nbmg_x_extent_device.argtypes = [C.c_size_t, _DP, C.c_double, _DP, _DP, C.c_void_p]
+        L.nbmg_halo_select_device.argtypes = ([C.c_size_t] + [_DP] * 4 + [C.c_double] * 4
+                                              + [_DP, C.c_size_t, SZ, C.c_void_p])
         self._inited = False
 
     def _check(self, rc):
@@ -568,6 +572,23 @@ class MultiGpuLibrary:
         self._check(self.lib.nbmg_accumulate_device(
             C.byref(p), n, _dev(own_x), _dev(own_y), _dev(own_z), _dev(m_full), _dev(ax), _dev(ay),
             _dev(az), C.c_void_p(stream or 0)))
+
+    def x_extent_device(self, x, domain_size, stream=None):
+        """Circular x interval (lo, hi) that holds every position of the device tensor x."""
+        lo, hi = C.c_double(), C.c_double()
+        self._check(self.lib.nbmg_x_extent_device(x.numel(), _dev(x), domain_size, C.byref(lo), C.byref(hi),
+                                                  C.c_void_p(stream or 0)))
+        return lo.value, hi.value
+
+    def halo_select_device(self, x, y, z, m, domain_size, lo, hi, margin, out=None, stream=None):
+        """Number of particles within `margin` of the circular interval [lo, hi]; with `out` (a device
+        tensor of 4 * capacity doubles) they are packed into it, x | y | z | m, in index order."""
+        n_sel = C.c_size_t()
+        cap = 0 if out is None else out.numel() // 4
+        self._check(self.lib.nbmg_halo_select_device(
+            x.numel(), _dev(x), _dev(y), _dev(z), _dev(m), domain_size, lo, hi, margin,
+            _dev(out) if out is not None else None, cap, C.byref(n_sel), C.c_void_p(stream or 0)))
+        return n_sel.value
 
     def max_accel_sq_device(self, a, count=None, stream=None):
         out = C.c_double(0.0)

@@ -74,7 +74,7 @@ def test_multi_gpu_header_and_library_agree():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/nbmg.h but not exported"
     assert sorted(ffi.MG_EXPORTS) == names
-    assert ctypes.sizeof(ffi.MultiGpuStats) == 4 * 8 + 2 * 8 + 2 * 4
+    assert ctypes.sizeof(ffi.MultiGpuStats) == 4 * 8 + 2 * 8 + 2 * 4 + 8
     L = ffi.MultiGpuLibrary()
     import torch
     if not torch.cuda.is_available():

@@ -98,6 +98,121 @@ def test_one_rank_collectives_are_identities(mg):
     assert mg.max_accel_sq_device(zero, count=0) == 1e-9
 
 
+def test_x_extent_is_the_complement_of_the_longest_gap(mg):
+    L = 2.0
+    rng = np.random.Generator(np.random.MT19937(3))
+    # a block that wraps through x = 0: [1.7, 2.0) and [0, 0.3)
+    xs = np.concatenate([1.7 + 0.3 * rng.random(500), 0.3 * rng.random(500)])
+    lo, hi = mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L)
+    bin_w = L / 4096
+    assert lo > hi and xs[xs > 1.0].min() - bin_w <= lo <= xs[xs > 1.0].min()
+    assert xs[xs < 1.0].max() <= hi <= xs[xs < 1.0].max() + bin_w
+    # an ordinary block, the ends of the box included
+    xs = 0.5 + 0.25 * rng.random(300)
+    lo, hi = mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L)
+    assert xs.min() - bin_w <= lo <= xs.min() and xs.max() <= hi <= xs.max() + bin_w
+    xs = np.array([0.0, L])
+    assert mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L) == (pytest.approx(L - bin_w), bin_w)
+    # spread over the whole box: no gap wider than the block itself is found -> an interval that
+    # still holds every particle
+    xs = L * rng.random(100000)
+    lo, hi = mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L)
+    width = hi - lo if hi > lo else hi - lo + L
+    assert width > 0.99 * L
+    assert mg.x_extent_device(torch.empty(0, dtype=torch.float64, device="cuda:0"), L) == (0.0, L)
+
+
+def test_halo_select_equals_numpy_selection(mg):
+    L = 1.0
+    n = 20000
+    rng = np.random.Generator(np.random.MT19937(5))
+    host = [rng.random(n) * L for _ in range(3)] + [rng.random(n) + 0.5]
+    dev = [torch.as_tensor(a, device="cuda:0") for a in host]
+    for lo, hi, margin in [(0.25, 0.5, 0.03), (0.9, 0.1, 0.05), (0.0, 0.125, 0.02), (0.3, 0.3, 0.0), (0.1, 0.9, 0.2)]:
+        width = (hi - lo if hi > lo else hi - lo + L) + 2 * margin
+        d = np.mod(host[0] - (lo - margin), L)
+        want = np.nonzero(d <= width)[0] if width < L else np.arange(n)
+        assert mg.halo_select_device(*dev, L, lo, hi, margin) == want.size
+        cap = want.size + 7
+        out = torch.full((4 * cap,), -1.0, dtype=torch.float64, device="cuda:0")
+        assert mg.halo_select_device(*dev, L, lo, hi, margin, out=out) == want.size
+        got = out.cpu().numpy().reshape(4, cap)
+        for c in range(4):
+            assert np.array_equal(got[c, :want.size], host[c][want])
+            assert np.all(got[c, want.size:] == -1.0)
+    small = torch.empty(4 * 10, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(ffi.NbppError, match="room for 10"):
+        mg.halo_select_device(*dev, L, 0.25, 0.5, 0.03, out=small)
+
+
+@pytest.mark.parametrize("n_blocks", [2, 5])
+def test_halo_exchange_between_virtual_ranks_equals_the_full_evaluation(lib, mg, n_blocks):
+    """What NBMG_OPT_HALO_EXCHANGE does on several ranks, with the ranks played one after another
+    on this GPU: every block learns its x interval, takes from every other block the particles
+    within the cutoff radius of that interval, and evaluates its own targets against own + halo.
+    The forces must be the ones of the evaluation against all particles (the halo holds every
+    source inside the cutoff; the others contribute exactly nothing), and the halos must be a
+    small part of the set."""
+    n_side = 40
+    n = n_side ** 3
+    x, y, z, m = _set(n_side, equal=False)
+    cfg = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    p = cfg.pp_params()
+    L = p.domain_size
+    margin = float(np.sqrt(p.cutoff_sq)) * (1 + 1e-9)
+    want = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    lib.accumulate_device(p, x, y, z, m, *want)
+    blocks = [mg.partition(n, r, n_blocks) for r in range(n_blocks)]
+    own = [[a[b:b + c] for a in (x, y, z, m)] for b, c in blocks]
+    extents = [mg.x_extent_device(o[0], L) for o in own]
+    got = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    received = 0
+    for r, (b, c) in enumerate(blocks):
+        parts = [own[r]]
+        for q in range(n_blocks):
+            if q == r:
+                continue
+            k = mg.halo_select_device(*own[q], L, *extents[r], margin)
+            out = torch.empty(4 * k, dtype=torch.float64, device="cuda:0")
+            assert mg.halo_select_device(*own[q], L, *extents[r], margin, out=out) == k
+            parts.append([out[i * k:(i + 1) * k] for i in range(4)])
+            received += k
+        src = [torch.cat([part[i] for part in parts]) for i in range(4)]
+        lib.accumulate_device(p, *src, *[g[b:b + c] for g in got], tgt_begin=0, n_tgt=c)
+    torch.cuda.synchronize()
+    err = normalised_error([g.cpu().numpy() for g in got], [w.cpu().numpy() for w in want])
+    assert err < TOL
+    # every block of a lattice in index order is an x slab: two halos of about one cutoff radius
+    slab = L / n_blocks
+    assert received < 1.3 * n * (2 * margin + 2 * L / n_side) / slab
+
+
+def test_halo_code_path_on_one_rank(lib, mg):
+    """NBMG_OPT_HALO_EXCHANGE = 2 takes the halo path of nbmg_accumulate_device on one rank too:
+    the interval all-gather, the count matrix and an empty send/receive group really run on RCCL,
+    and the forces equal the plain path's."""
+    n_side = 24
+    n = n_side ** 3
+    x, y, z, m = _set(n_side, equal=True)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True).pp_params()
+    lib.set_option(ffi.OPT_DETERMINISTIC, 1)
+    try:
+        want = [torch.full((n,), 0.5, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+        lib.accumulate_device(p, x, y, z, m, *want)
+        mg.set_option(ffi.MG_OPT_HALO_EXCHANGE, 2)
+        for _ in range(2):   # twice: the second call reuses the library's buffers
+            got = [torch.full((n,), 0.5, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+            mg.accumulate_device(p, n, x, y, z, m, *got)
+            torch.cuda.synchronize()
+            st = mg.stats()
+            assert st["halo_particles"] == 0 and st["allgather_bytes"] == 0 and st["total_ms"] > 0.0
+            for g, w in zip(got, want):
+                assert torch.equal(g, w)
+    finally:
+        mg.set_option(ffi.MG_OPT_HALO_EXCHANGE, 0)
+        lib.set_option(ffi.OPT_DETERMINISTIC, 0)
+
+
 def _run_engine(tmp_path, ini_text, cycles, env_extra):
     import os
     import re
