@@ -593,9 +593,10 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
                            tlist);
     }
     HIPCHK(hipGetLastError());
-    CHK(g.counter.ensure(2 * sizeof(unsigned long long)));
+    constexpr size_t counter_bytes = sizeof(unsigned long long) * P3M_COUNT_STRIPES * P3M_COUNT_STRIDE;
+    CHK(g.counter.ensure(counter_bytes));
     if (g.opt_timing) {   // the accepted-pair counter is only kept when timing
-        HIPCHK(hipMemsetAsync(g.counter.p, 0, 2 * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(g.counter.p, 0, counter_bytes, s));
         HIPCHK(hipEventRecord(g.ev[1], s));
     }
 
@@ -744,8 +745,10 @@ int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const
         g.stats.pair_kernel_ms = b;
         g.stats.total_ms = a + b;
         if (variant == NBPP_KERNEL_P3M_CELLS) {
+            unsigned long long stripes[P3M_COUNT_STRIPES * P3M_COUNT_STRIDE];
+            HIPCHK(hipMemcpy(stripes, g.counter.p, sizeof(stripes), hipMemcpyDeviceToHost));
             unsigned long long hits = 0;
-            HIPCHK(hipMemcpy(&hits, g.counter.p, sizeof(hits), hipMemcpyDeviceToHost));
+            for (int i = 0; i < P3M_COUNT_STRIPES; ++i) hits += stripes[i * P3M_COUNT_STRIDE];
             g.stats.pairs_accepted = hits;
         } else {
             unsigned long long tc[2] = {0, 0};

@@ -1013,6 +1013,15 @@ struct P3MArgs {
     PairConsts k;
 };
 
+// The accepted-pair counter is P3M_COUNT_STRIPES partial counters 128 bytes apart, one per
+// workgroup number modulo the stripes: a few hundred thousand atomics on ONE address take
+// longer than the pair kernel itself (about 11 ns each, one after the other, in the L2).
+constexpr int P3M_COUNT_STRIPES = 64;
+constexpr int P3M_COUNT_STRIDE = 16;   // in 8-byte words
+__device__ __forceinline__ unsigned long long* accepted_stripe(unsigned long long* base) {
+    return base + (blockIdx.x % P3M_COUNT_STRIPES) * P3M_COUNT_STRIDE;
+}
+
 constexpr int P3M_QCAP = 16;    // accepted-pair ring per lane (power of 2; 16 KiB LDS per workgroup)
 constexpr int P3M_DRAIN_UNROLL = 2;   // record fetches in flight per lane while draining (1: 62 instead of 72
                                       // registers and an eighth wavefront per SIMD, yet 5 % slower; 4: 3 % slower)
@@ -1095,6 +1104,38 @@ __device__ __forceinline__ double4 load_record_checked(__amdgpu_buffer_rsrc_t rs
     const v2d lo = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 0));
     const v2d hi = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset + 16u, 0, 0));
     return make_double4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// Of a row's 2R + 1 cells a target only has to walk those its cutoff sphere meets.  With
+// (tx, ty, tz) the target's place inside its own cell (in cells, [0, 1]) and dm the distance
+// from it to the nearest face of the row's column (ox, oy cells away), the sphere spans
+// tz +- sqrt(rc^2 - dm^2) there, nothing when that is negative: 44 % fewer candidates at two
+// cells per cutoff radius.  Single precision with a margin of 1e-4 cells (positions and cell
+// numbers come from the same double-precision product, so they agree to far better than that).
+// The lanes of a wavefront still walk a row for as long as the longest of their windows, so the
+// time saved is a few per cent (k_p3m_pool, k_p3m_sym); k_p3m_cells, whose extra registers cost it
+// a wavefront per SIMD, walks whole rows.
+struct RowTrim {
+    float tx, ty, tz;
+    float rc2;      // (cutoff radius in cells)^2, rounded up
+};
+__device__ __forceinline__ RowTrim make_row_trim(const double4& me, int pcx, int pcy, int pcz, const GhostGrid& g,
+                                                 const PairConsts& k) {
+    const auto inside = [&](double c, int cell) {
+        return fminf(fmaxf(static_cast<float>(c * g.scale - static_cast<double>(cell - g.R)), 0.0f), 1.0f);
+    };
+    const float rc = static_cast<float>(sqrt(k.cutoff_sq) * g.scale);
+    return RowTrim{inside(me.x, pcx), inside(me.y, pcy), inside(me.z, pcz), rc * rc * (1.0f + 1e-5f)};
+}
+// cells [zlo, zhi] (relative to the target's) of the row (ox, oy) the sphere meets; false: none
+__device__ __forceinline__ bool row_window(const RowTrim& w, int ox, int oy, int R, int& zlo, int& zhi) {
+    const float dxm = ox > 0 ? static_cast<float>(ox) - w.tx : (ox < 0 ? w.tx - static_cast<float>(ox + 1) : 0.0f);
+    const float dym = oy > 0 ? static_cast<float>(oy) - w.ty : (oy < 0 ? w.ty - static_cast<float>(oy + 1) : 0.0f);
+    const float h2 = w.rc2 - dxm * dxm - dym * dym;
+    const float h = __builtin_sqrtf(fmaxf(h2, 0.0f)) + 1e-4f;
+    zlo = max(-R, static_cast<int>(floorf(w.tz - h)));
+    zhi = min(R, static_cast<int>(floorf(w.tz + h)));
+    return h2 >= 0.0f;
 }
 
 // S (1, 2, 4 or 8) lanes share one target, lane `sub` taking rows sub, sub + S, ...; their sums
@@ -1260,7 +1301,7 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
     if (a.accepted) {
         unsigned long long h = live ? hits : 0u;
         for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
-        if ((threadIdx.x & 63) == 0 && h) atomicAdd(a.accepted, h);
+        if ((threadIdx.x & 63) == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
     }
 }
 
@@ -1366,11 +1407,18 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
     const int n_rows = span * span;
     const int row_jump = g.np * (g.np - span + 1);
     int base = ((pcx - g.R) * g.np + (pcy - g.R)) * g.np + pcz;
-    int round = 0, oy = 0;
+    int round = 0, ox = 0, oy = 0;
     int j = 0, je = 0;
-    // padding lanes copy the last target: their runs are empty
-    int nj = live ? load_word(a.cell_start, base - g.R) : 0;
-    int nje = live ? load_word(a.cell_start, base + g.R + 1) : 0;
+    int nj = 0, nje = 0;
+    const RowTrim trim = make_row_trim(me, pcx, pcy, pcz, g, k);
+    // the part of row (ox, oy) this target can reach; padding lanes copy the last target: their runs are empty
+    auto request_row = [&](bool has) {
+        int zlo, zhi;
+        has = row_window(trim, ox - g.R, oy - g.R, g.R, zlo, zhi) && has;
+        nj = has ? load_word(a.cell_start, base + zlo) : 0;
+        nje = has ? load_word(a.cell_start, base + zhi + 1) : 0;
+    };
+    request_row(live);
 #pragma unroll 1
     for (;;) {
         if (!__any(j < je)) {   // every lane has finished its run: the next row
@@ -1380,8 +1428,8 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
             const bool wrap = oy + 1 == span;
             base += (round < n_rows) ? (wrap ? row_jump : g.np) : 0;
             oy = wrap ? 0 : oy + 1;
-            nj = live ? load_word(a.cell_start, base - g.R) : 0;
-            nje = live ? load_word(a.cell_start, base + g.R + 1) : 0;
+            ox += wrap ? 1 : 0;
+            request_row(live && round < n_rows);
         }
         p3m_vf cx, cy, cz;
         if constexpr (WIDE) {
@@ -1423,7 +1471,7 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
         // pairs are counted by the lane that evaluated them; every live target met itself once
         long long h = static_cast<long long>(hits) - (live ? 1 : 0);
         for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
-        if (lane == 0 && h) atomicAdd(a.accepted, static_cast<unsigned long long>(h));
+        if (lane == 0 && h) atomicAdd(accepted_stripe(a.accepted), static_cast<unsigned long long>(h));
     }
 }
 
@@ -1615,6 +1663,7 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
         const int rcx = piece / SYM_BY, rcy = piece - rcx * SYM_BY + g.R;   // own column inside the region
         const int pcx = x0 + rcx, pcy = y0 + rcy - g.R;
         const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
+        const RowTrim trim = make_row_trim(me, pcx, pcy, pcz, g, k);
         double ax = 0.0, ay = 0.0, az = 0.0;
         int rp = 0, wp = 0;
         int lim = P3M_QCAP - P3M_TRIP;
@@ -1662,10 +1711,11 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
         auto row_bounds = [&](int r, int& first, int& last, int& tg) {
             ++oy;
             if (oy > g.R) { oy = -g.R; ++ox; }
-            const bool has = live && r < n_rows;
+            int zlo, zhi;                       // the part of the row this particle can reach
+            const bool has = row_window(trim, ox, oy, g.R, zlo, zhi) && live && r < n_rows;
             const int base = ((pcx + ox) * g.np + (pcy + oy)) * g.np + pcz;
-            first = has ? load_word(a.cell_start, base - g.R) : 0;
-            last = has ? load_word(a.cell_start, base + g.R + 1) : 0;
+            first = has ? load_word(a.cell_start, base + zlo) : 0;
+            last = has ? load_word(a.cell_start, base + zhi + 1) : 0;
             if (r == 0) first = has ? p + 1 : 0;
             tg = ((rcx + ox) * CY + (rcy + oy)) << SYM_JBITS;
         };
@@ -1767,7 +1817,7 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
     if (a.accepted) {
         unsigned long long h = 2ull * hits;          // both members of every pair
         for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
-        if ((tid & 63) == 0 && h) atomicAdd(a.accepted, h);
+        if ((tid & 63) == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
     }
 }
 
