@@ -54,7 +54,8 @@ __device__ __forceinline__ double rotate_lane(double v) {
 
 // (Eight tiles per group instead of four would halve the rotations per pair again, but needs
 // more than 168 registers: at 3 waves/SIMD with spills it ran at 2.27 instead of 2.89 T
-// interactions/s.)
+// interactions/s; six fit 168 registers without spills in the loop and ran at 2.77 T/s at
+// 3 waves/SIMD: the wavefront lost costs more than the rotations saved.)
 // (Moving the coordinates through the LDS crossbar instead, ds_bpermute_b32 issued at the start
 // of a step, was measured slower: the extra live registers spill at 4 waves/SIMD and 3 waves/SIMD
 // loses more than the six DPP moves cost.)
