@@ -527,7 +527,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
                            static_cast<int>(ncell), count, start, occ);
         const bool sym_possible = all_targets && R <= SYM_MAXR && g.opt_p3m_sym >= 0;
         if (sym_possible)
-            hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(1LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
+            hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(16LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
                                nbx, nby, nbz, occ + 2);
         unsigned long long* host = static_cast<unsigned long long*>(g.pinned);
         HIPCHK(hipMemcpyAsync(host, occ, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -1507,6 +1507,7 @@ constexpr int SYM_DU = 4;           // record fetches in flight per lane while d
 constexpr int SYM_MAXR = 3;         // search radius in cells the tables are sized for
 constexpr int SYM_MAXCOL = (SYM_BX + SYM_MAXR) * (SYM_BY + 2 * SYM_MAXR);
 constexpr int SYM_JBITS = 25;       // ring entries: region column << 25 | sorted position
+static_assert(SYM_BY + 2 * SYM_MAXR <= 16, "k_sym_region_max gives a brick 16 lanes, one per y column of its region");
 
 // S (f_pp - f_pm) of src/particles.cpp:330-355 for r^2 <= cutoff_sq (without G m and d).
 template <bool SOFT0>
@@ -1534,20 +1535,25 @@ __device__ __forceinline__ double p3m_factor(double r2, const PairConsts& k) {
 // one does not fit SYM_CAP (a clustered set).
 __global__ void k_sym_region_max(GhostGrid g, const int* __restrict__ cell_start, int nbx, int nby, int nbz,
                                  unsigned long long* __restrict__ out) {
-    const int brick = blockIdx.x * blockDim.x + threadIdx.x;
-    if (brick >= nbx * nby * nbz) return;
-    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
-    const int x0 = g.R + bx * SYM_BX, y0 = g.R + by * SYM_BY, z0 = g.R + bz * SYM_BZ;
-    const int zlo = z0 - g.R, zhi = min(z0 + SYM_BZ, g.R + g.nside) + g.R;
+    // 16 lanes per brick, one per y column of the region (SYM_BY + 2 SYM_MAXR <= 16), each over the region's x
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int brick = gt >> 4, ry = gt & 15;
     int total = 0;
-    for (int rx = 0; rx < SYM_BX + g.R; ++rx)
-        for (int ry = 0; ry < SYM_BY + 2 * g.R; ++ry) {
-            const int px = x0 + rx, py = y0 - g.R + ry;
+    if (brick < nbx * nby * nbz && ry < SYM_BY + 2 * g.R) {
+        const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+        const int x0 = g.R + bx * SYM_BX, y0 = g.R + by * SYM_BY, z0 = g.R + bz * SYM_BZ;
+        const int zlo = z0 - g.R, zhi = min(z0 + SYM_BZ, g.R + g.nside) + g.R;
+        const int py = y0 - g.R + ry;
+        for (int rx = 0; rx < SYM_BX + g.R; ++rx) {
+            const int px = x0 + rx;
             if (px >= g.np || py >= g.np) continue;
             const int col = (px * g.np + py) * g.np;
             total += cell_start[col + zhi] - cell_start[col + zlo];
         }
-    atomicMax(out, static_cast<unsigned long long>(total));
+    }
+    for (int d = 1; d < 16; d <<= 1) total += __shfl_xor(total, d, 64);
+    for (int d = 16; d < 64; d <<= 1) total = max(total, __shfl_xor(total, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, static_cast<unsigned long long>(total));
 }
 
 template <bool SOFT0>
