@@ -213,6 +213,97 @@ def test_halo_code_path_on_one_rank(lib, mg):
         lib.set_option(ffi.OPT_DETERMINISTIC, 0)
 
 
+def _halo_worker(rank, world, port, n_side, out_dir):
+    """One of `world` processes on the one GPU: its block of the particles, the x interval and the
+    halo selection of libnbmg on the device, the packs carried between the processes by gloo (RCCL
+    refuses two ranks on one device), own + received particles through nbpp_accumulate_device."""
+    import os
+    import sys
+    import torch.distributed as dist
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nbody_amd
+    lib = nbody_amd.load(device=0)
+    mg = ffi.load_multi_gpu()
+    mg.init(0, 1, None, 0)                      # a communicator of its own; the exchange below is gloo's
+    n = n_side ** 3
+    x, y, z, m = _set(n_side, equal=False)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True).pp_params()
+    L = p.domain_size
+    margin = float(np.sqrt(p.cutoff_sq)) * (1 + 1e-9)
+    b, c = mg.partition(n, rank, world)
+    own = [a[b:b + c].contiguous() for a in (x, y, z, m)]
+    mine = torch.tensor(mg.x_extent_device(own[0], L), dtype=torch.float64)
+    extents = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(extents, mine)
+    # what every peer needs from me, and how much I get from each
+    packs, give = [], torch.zeros(world, dtype=torch.int64)
+    for q in range(world):
+        if q == rank:
+            packs.append(None)
+            continue
+        lo, hi = (float(v) for v in extents[q])
+        k = mg.halo_select_device(*own, L, lo, hi, margin)
+        out = torch.empty(4 * k, dtype=torch.float64, device="cuda:0")
+        assert mg.halo_select_device(*own, L, lo, hi, margin, out=out) == k
+        packs.append(out.cpu())
+        give[q] = k
+    counts = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, give)
+    take = [int(counts[q][rank]) for q in range(world)]
+    received = {}
+    for q in range(world):                      # pairwise exchange, lower rank sends first
+        if q == rank:
+            continue
+        buf = torch.empty(4 * take[q], dtype=torch.float64)
+        if rank < q:
+            dist.send(packs[q], q)
+            dist.recv(buf, q)
+        else:
+            dist.recv(buf, q)
+            dist.send(packs[q], q)
+        received[q] = buf.to("cuda:0")
+    parts = [own] + [[received[q][i * take[q]:(i + 1) * take[q]] for i in range(4)] for q in sorted(received)]
+    src = [torch.cat([part[i] for part in parts]) for i in range(4)]
+    acc = [torch.zeros(c, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    lib.accumulate_device(p, *src, *acc, tgt_begin=0, n_tgt=c)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"halo_acc_{rank}.npy"), np.stack([a.cpu().numpy() for a in acc]))
+    np.save(os.path.join(out_dir, f"halo_bytes_{rank}.npy"), np.array([32 * sum(take), 24 * (n - c)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_between_processes_equals_one_rank(lib, tmp_path, world):
+    """World size 2 and 3 on the one GPU of the box: every process owns a block, exchanges only
+    the particles within a cutoff radius of its peers' blocks, and the forces equal the one-rank
+    evaluation to the path's 1e-10.  The bytes a rank receives are reported beside what the
+    all-gather of every position would have brought it."""
+    import socket
+    import torch.multiprocessing as mp
+    n_side = 40
+    n = n_side ** 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_halo_worker, args=(world, port, n_side, str(tmp_path)), nprocs=world, join=True)
+    x, y, z, m = _set(n_side, equal=False)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True).pp_params()
+    want = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    lib.accumulate_device(p, x, y, z, m, *want)
+    torch.cuda.synchronize()
+    got = np.concatenate([np.load(tmp_path / f"halo_acc_{r}.npy") for r in range(world)], axis=1)
+    assert normalised_error(list(got), [w.cpu().numpy() for w in want]) < TOL
+    for r in range(world):
+        halo_bytes, allgather_bytes = np.load(tmp_path / f"halo_bytes_{r}.npy")
+        print(f"rank {r} of {world}: {halo_bytes} B of halo particles against {allgather_bytes} B all-gathered")
+        assert 0 < halo_bytes < (0.5 if world == 2 else 1.0) * allgather_bytes
+
+
 def _run_engine(tmp_path, ini_text, cycles, env_extra):
     import os
     import re
