@@ -98,7 +98,7 @@ struct Ctx {
 };
 
 Ctx g;
-std::mutex g_mu;
+std::recursive_mutex g_mu;   // recursive: the halo exchange calls the public selection entry points
 
 // ---- halo selection: which of my particles lie within `margin` of a peer's x interval ----------
 constexpr int XBINS = 4096;      // resolution of a block's x extent
@@ -209,7 +209,7 @@ int nbmg_get_unique_id(void* id) {
 }
 
 int nbmg_init(int rank, int nranks, const void* id, int device) {
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
     if (g.ready) {
         if (rank == g.rank && nranks == g.nranks) return NBMG_OK;
         return fail(NBMG_ERR_ARG, "already initialised as rank %d of %d", g.rank, g.nranks);
@@ -290,7 +290,7 @@ int nbmg_init_from_env(void) {
 }
 
 void nbmg_shutdown(void) {
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
     (void)hipDeviceSynchronize();
@@ -370,6 +370,7 @@ int nbmg_x_extent_device(size_t count, const double* x, double domain_size, doub
     *hi = domain_size;
     if (count == 0) return NBMG_OK;
     if (!x) return fail(NBMG_ERR_ARG, "NULL array pointer");
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
     HIPCHK(hipSetDevice(g.device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     CHK(g_bins.ensure(XBINS));
@@ -405,6 +406,7 @@ int nbmg_halo_select_device(size_t count, const double* x, const double* y, cons
     if (!x || !y || !z || !m) return fail(NBMG_ERR_ARG, "NULL array pointer");
     if (!(domain_size > 0.0) || !(margin >= 0.0)) return fail(NBMG_ERR_ARG, "domain_size must be positive, margin >= 0");
     if (count > 0x7ffffff0ull) return fail(NBMG_ERR_ARG, "at most 2^31 - 16 particles per block");
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
     HIPCHK(hipSetDevice(g.device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     double width = hi - lo;                                  // circular length of [lo, hi]
@@ -514,7 +516,7 @@ int nbmg_accumulate_device(const nbpp_params* p, size_t n, const double* own_x, 
     if (!g.ready) return fail(NBMG_ERR_NOINIT, "nbmg_init has not been called");
     if (!p) return fail(NBMG_ERR_ARG, "params is NULL");
     if (n == 0) return NBMG_OK;
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
     HIPCHK(hipSetDevice(g.device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     size_t begin = 0, count = 0;
@@ -608,7 +610,7 @@ int nbmg_max_accel_sq_device(size_t count, const double* ax, const double* ay, c
     PPCHK(nbpp_max_accel_sq_device(count, ax, ay, az, &local, stream));   // floor 1e-9, also for count == 0
     *out_host = local;
     if (g.nranks == 1) return NBMG_OK;
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
     HIPCHK(hipSetDevice(g.device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     *g.pinned = local;
