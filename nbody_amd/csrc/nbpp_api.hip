@@ -548,7 +548,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     uint8_t* codes = g.ghostcode.as<uint8_t>();
     double4* rec = g.src.x.as<double4>();
     // and their fp32 copies, one array per axis, in the y buffer
-    const size_t f_stride = (static_cast<size_t>(n_entries) + P3M_TRIP + 63) / 64 * 64;
+    const size_t f_stride = (static_cast<size_t>(n_entries) + std::max(P3M_TRIP, P3M_POOL_TRIP) + 63) / 64 * 64;
     CHK(g.src.y.ensure(sizeof(float) * 3 * f_stride));
     float* fx = g.src.y.as<float>();
     float* fy = fx + f_stride;
@@ -655,11 +655,13 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
                                        (g.opt_p3m_pooled == 0 && !g.opt_deterministic && occupancy >= 6.0));
     g.stats.p3m_pooled = pooled ? 1 : 0;
     if (pooled) {
+        // its ring entries keep the sorted position in 26 bits; beyond that the two-word form
+        const bool pool_wide = wide || n_entries + P3M_POOL_TRIP >= (1 << P3M_POOL_LANE_SHIFT);
         if (soft0) {
-            if (wide) hipLaunchKernelGGL((k_p3m_pool<true, true>), grid_dim, wg_dim, 0, s, a);
+            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<true, true>), grid_dim, wg_dim, 0, s, a);
             else hipLaunchKernelGGL((k_p3m_pool<true, false>), grid_dim, wg_dim, 0, s, a);
         } else {
-            if (wide) hipLaunchKernelGGL((k_p3m_pool<false, true>), grid_dim, wg_dim, 0, s, a);
+            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<false, true>), grid_dim, wg_dim, 0, s, a);
             else hipLaunchKernelGGL((k_p3m_pool<false, false>), grid_dim, wg_dim, 0, s, a);
         }
         HIPCHK(hipGetLastError());

@@ -1322,11 +1322,16 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
 // collide).  The order in which colliding lanes add is the hardware's: sums are not bitwise
 // reproducible from run to run (NBPP_OPT_DETERMINISTIC keeps k_p3m_cells).
 // ---------------------------------------------------------------------------------
-constexpr int P3M_POOL_CAP = 512;   // pairs per wavefront ring (power of 2): < 128 left by a drain + 4 * 64 from a trip
+constexpr int P3M_POOL_CAP = 512;   // pairs per wavefront ring (power of 2): < 128 left by a drain + 4 * 64 from half a trip
+constexpr int P3M_POOL_TRIP = 8;    // candidates a lane tests per trip: the runs of a clustered set are long
+constexpr int P3M_POOL_LANE_SHIFT = 26;   // ring entry = target lane << 26 | sorted position of the source (< 2^26)
+typedef float p3m_pool_vf __attribute__((ext_vector_type(P3M_POOL_TRIP)));
 
 template <bool SOFT0, bool WIDE>
 __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
-    __shared__ uint2 pool[WG / 64][P3M_POOL_CAP];   // {target lane, sorted position of the source}
+    // ring entries: target lane << 26 | sorted position of the source; {lane, position} when positions need more bits
+    using Entry = std::conditional_t<WIDE, uint2, unsigned>;
+    __shared__ Entry pool[WG / 64][P3M_POOL_CAP];
     __shared__ double2 txy[WG];                      // target x, y
     __shared__ double tz[WG];                        // target z
     __shared__ double tsum[3][WG];                   // the targets' sums
@@ -1339,7 +1344,7 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
     const bool live = t < a.n_tgt;
     const int p = a.tlist[live ? t : a.n_tgt - 1];
     const double4 me = a.rec[p];
-    const p3m_vf nmx = -a.fx[p], nmy = -a.fy[p], nmz = -a.fz[p];
+    const p3m_pool_vf nmx = -a.fx[p], nmy = -a.fy[p], nmz = -a.fz[p];
     const GhostGrid g = a.g;
     const PairConsts k = a.k;
     const float bound = a.prefilter_sq;
@@ -1347,7 +1352,7 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
     const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
     const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wave_base = wave << 6;
-    uint2* const ring = pool[wave];
+    Entry* const ring = pool[wave];
     txy[threadIdx.x] = make_double2(me.x, me.y);
     tz[threadIdx.x] = me.z;
     tsum[0][threadIdx.x] = 0.0;
@@ -1356,7 +1361,7 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
     __builtin_amdgcn_wave_barrier();   // only this wavefront reads them back, and LDS operations of a wavefront stay in order
     int rp = 0, wp = 0;                // ring read / write positions, unwrapped, the same in every lane
     unsigned hits = 0;
-    const uint32_t f_bytes = WIDE ? 0u : static_cast<uint32_t>(a.n_entries + P3M_TRIP) << 2;
+    const uint32_t f_bytes = WIDE ? 0u : static_cast<uint32_t>(a.n_entries + P3M_POOL_TRIP) << 2;
     const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fz), 0, f_bytes, 0x00020000);
@@ -1371,7 +1376,7 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
     // the pair count at the end.
     auto drain = [&](auto nb_tag, int count) {
         constexpr int NB = decltype(nb_tag)::value;
-        uint2 e[NB];
+        unsigned tl[NB], sj[NB];      // target lane, source
         bool valid[NB];
         double4 s[NB];
         double2 gxy[NB];
@@ -1379,12 +1384,18 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             valid[u] = u * 64 + lane < count;
-            e[u] = ring[(rp + u * 64 + lane) & (P3M_POOL_CAP - 1)];
-            if (!valid[u]) e[u] = make_uint2(static_cast<unsigned>(lane), static_cast<unsigned>(p));
-            gxy[u] = txy[wave_base + static_cast<int>(e[u].x)];
-            gz[u] = tz[wave_base + static_cast<int>(e[u].x)];
-            if constexpr (WIDE) s[u] = a.rec[static_cast<int>(e[u].y)];
-            else s[u] = load_record_checked(rec_rsrc, valid[u] ? e[u].y << 5 : 0xffffffe0u);
+            const Entry e = ring[(rp + u * 64 + lane) & (P3M_POOL_CAP - 1)];
+            if constexpr (WIDE) {
+                tl[u] = valid[u] ? e.x : static_cast<unsigned>(lane);
+                sj[u] = valid[u] ? e.y : static_cast<unsigned>(p);
+            } else {
+                tl[u] = valid[u] ? e >> P3M_POOL_LANE_SHIFT : static_cast<unsigned>(lane);
+                sj[u] = valid[u] ? e & ((1u << P3M_POOL_LANE_SHIFT) - 1u) : static_cast<unsigned>(p);
+            }
+            gxy[u] = txy[wave_base + static_cast<int>(tl[u])];
+            gz[u] = tz[wave_base + static_cast<int>(tl[u])];
+            if constexpr (WIDE) s[u] = a.rec[static_cast<int>(sj[u])];
+            else s[u] = load_record_checked(rec_rsrc, valid[u] ? sj[u] << 5 : 0xffffffe0u);
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -1393,7 +1404,7 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
             if (valid[u] && !(r2 > k.cutoff_sq)) {   // the reference's cutoff test (src/particles.cpp:326)
                 double cx = 0.0, cy = 0.0, cz = 0.0;
                 p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, cx, cy, cz);
-                const int slot = wave_base + static_cast<int>(e[u].x);
+                const int slot = wave_base + static_cast<int>(tl[u]);
                 __hip_atomic_fetch_add(&tsum[0][slot], cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&tsum[1][slot], cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&tsum[2][slot], cz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1431,32 +1442,38 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
             ox += wrap ? 1 : 0;
             request_row(live && round < n_rows);
         }
-        p3m_vf cx, cy, cz;
+        p3m_pool_vf cx, cy, cz;
         if constexpr (WIDE) {
             const int bb = j < je ? j : p;
-            cx = load_fvec(a.fx, bb); cy = load_fvec(a.fy, bb); cz = load_fvec(a.fz, bb);
+#pragma unroll
+            for (int u = 0; u < P3M_POOL_TRIP; ++u) {
+                cx[u] = a.fx[static_cast<size_t>(bb) + u]; cy[u] = a.fy[static_cast<size_t>(bb) + u]; cz[u] = a.fz[static_cast<size_t>(bb) + u];
+            }
         } else {
             const uint32_t off = j < je ? static_cast<uint32_t>(j) << 2 : 0xfffffff0u;
-            cx = load_fvec_checked(fx_rsrc, off);
-            cy = load_fvec_checked(fy_rsrc, off);
-            cz = load_fvec_checked(fz_rsrc, off);
+            cx = p3m_fvec_load<P3M_POOL_TRIP>::get(fx_rsrc, off);
+            cy = p3m_fvec_load<P3M_POOL_TRIP>::get(fy_rsrc, off);
+            cz = p3m_fvec_load<P3M_POOL_TRIP>::get(fz_rsrc, off);
         }
-        const p3m_vf dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
-        const p3m_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+        const p3m_pool_vf dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
+        const p3m_pool_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+        const unsigned tag = static_cast<unsigned>(lane) << P3M_POOL_LANE_SHIFT;
 #pragma unroll
-        for (int u = 0; u < P3M_TRIP; ++u) {
+        for (int u = 0; u < P3M_POOL_TRIP; ++u) {
             const bool pass = (j + u < je) & !(r2[u] > bound);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             // the survivors of this slot go to consecutive ring entries in lane order
             const int at = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
                                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), static_cast<unsigned>(wp)));
-            uint2* const where = &ring[at & (P3M_POOL_CAP - 1)];
-            const uint2 entry = make_uint2(static_cast<unsigned>(lane), static_cast<unsigned>(j + u));
-            if (pass) *where = entry;
+            Entry entry;
+            if constexpr (WIDE) entry = make_uint2(static_cast<unsigned>(lane), static_cast<unsigned>(j + u));
+            else entry = tag | static_cast<unsigned>(j + u);
+            if (pass) ring[at & (P3M_POOL_CAP - 1)] = entry;
             wp += __popcll(m);
+            if (u % 4 == 3)       // at most 127 left + 4 * 64 new entries in a ring of 512
+                while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, 128);
         }
-        j += P3M_TRIP;
-        while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, 128);
+        j += P3M_POOL_TRIP;
     }
     while (wp - rp > 0) drain(std::integral_constant<int, 1>{}, wp - rp);
     __builtin_amdgcn_wave_barrier();
