@@ -644,15 +644,16 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         g.stats.pair_launches = 1;
         return NBPP_OK;
     }
-    // one lane per target on a clustered set: the survivors of the filter are pooled per
-    // wavefront and evaluated 64 at a time whatever target they belong to (k_p3m_pool), unless
-    // reproducible sums are asked for.  Measured, kernel time pooled against per lane: 256^3
-    // near-uniform lattice (occupancy measure 3) 5.82 against 5.09 ms, the 128^3 run at a = 0.51
-    // 1.82 against 1.91 ms, 400 tight blobs 13.6 against 14.9 ms: pooling pays once lanes of a
-    // wavefront differ widely in their survivor counts, and costs on even loads, where its
-    // compaction makes the filter loop a third longer.
+    // one lane per target and particles that are not spread evenly: the survivors of the filter
+    // are pooled per wavefront and evaluated 64 at a time whatever target they belong to
+    // (k_p3m_pool), unless reproducible sums are asked for.  Measured, kernel time pooled against
+    // per lane: 256^3 jittered lattice (occupancy measure 2.6) 5.20 against 5.17 ms; the 128^3 run
+    // at a = 0.25 (2.9) 0.93 against 1.00 ms, at a = 0.33 (3.4) 1.07 against 1.22, at a = 0.40 (4.4)
+    // 1.23 against 1.47, at a = 0.51 (7.3) 1.54 against 1.97; 400 tight blobs 13.1 against 14.8 ms.
+    constexpr double POOL_FROM_OCCUPANCY = 2.7;
     const bool pooled = lanes == 1 && (g.opt_p3m_pooled > 0 ||
-                                       (g.opt_p3m_pooled == 0 && !g.opt_deterministic && occupancy >= 6.0));
+                                       (g.opt_p3m_pooled == 0 && !g.opt_deterministic &&
+                                        occupancy >= POOL_FROM_OCCUPANCY));
     g.stats.p3m_pooled = pooled ? 1 : 0;
     if (pooled) {
         // its ring entries keep the sorted position in 26 bits; beyond that the two-word form
