@@ -1324,6 +1324,7 @@ __global__ void __launch_bounds__(WG) k_p3m_cells(const P3MArgs a) {
 // ---------------------------------------------------------------------------------
 constexpr int P3M_POOL_CAP = 512;   // pairs per wavefront ring (power of 2): < 128 left by a drain + 4 * 64 from half a trip
 constexpr int P3M_POOL_TRIP = 8;    // candidates a lane tests per trip: the runs of a clustered set are long
+                                    // (16: 120 registers, 4 waves/SIMD, slower on every set: a = 0.51 1.66 against 1.54 ms)
 constexpr int P3M_POOL_LANE_SHIFT = 26;   // ring entry = target lane << 26 | sorted position of the source (< 2^26)
 typedef float p3m_pool_vf __attribute__((ext_vector_type(P3M_POOL_TRIP)));
 
