@@ -239,6 +239,8 @@ int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n,
  *                       short-range sums accumulate into arrays of their own (from zero) while
  *                       the mesh force was being computed on another stream: mesh + sum is the
  *                       same single rounding as the reference's mesh += sum.
+ * nbpp_add_clear_device a += b, then b = 0: the same, leaving the sums' arrays ready for the
+ *                       next evaluation without a separate pass over them.
  */
 int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz,
                      const double* ax, const double* ay, const double* az,
@@ -250,6 +252,8 @@ int nbpp_max_accel_sq_device(size_t n, const double* ax, const double* ay,
                              const double* az, double* out_host, void* stream);
 int nbpp_add_device(size_t n, double* ax, double* ay, double* az,
                     const double* bx, const double* by, const double* bz, void* stream);
+int nbpp_add_clear_device(size_t n, double* ax, double* ay, double* az,
+                          double* bx, double* by, double* bz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -961,7 +961,7 @@ int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const doubl
         for (int c = 0; c < 3; ++c)
             HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view[c]), hout[c], 0));
         const int blocks = std::min(4096, cdiv(static_cast<long long>(n), WG));
-        hipLaunchKernelGGL(k_add, dim3(blocks), dim3(WG), 0, g.stream, n, dev_view[0], dev_view[1], dev_view[2],
+        hipLaunchKernelGGL(k_add<false>, dim3(blocks), dim3(WG), 0, g.stream, n, dev_view[0], dev_view[1], dev_view[2],
                            g.host_acc[0].as<double>(), g.host_acc[1].as<double>(), g.host_acc[2].as<double>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -1000,17 +1000,31 @@ int nbpp_accumulate(const nbpp_params* p, size_t n, const double* x, const doubl
     return NBPP_OK;
 }
 
-int nbpp_add_device(size_t n, double* ax, double* ay, double* az, const double* bx,
-                    const double* by, const double* bz, void* stream) {
+namespace {
+int add_arrays(bool clear, size_t n, double* ax, double* ay, double* az, double* bx, double* by, double* bz,
+               void* stream) {
     if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
     if (n == 0) return NBPP_OK;
     if (!ax || !ay || !az || !bx || !by || !bz) return fail(NBPP_ERR_ARG, "NULL array pointer");
     HIPCHK(hipSetDevice(g.device));
     hipStream_t s = static_cast<hipStream_t>(stream);   // NULL: the HIP null stream
     const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
-    hipLaunchKernelGGL(k_add, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz);
+    if (clear) hipLaunchKernelGGL(k_add<true>, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz);
+    else hipLaunchKernelGGL(k_add<false>, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz);
     HIPCHK(hipGetLastError());
     return NBPP_OK;
+}
+}  // namespace
+
+int nbpp_add_device(size_t n, double* ax, double* ay, double* az, const double* bx,
+                    const double* by, const double* bz, void* stream) {
+    return add_arrays(false, n, ax, ay, az, const_cast<double*>(bx), const_cast<double*>(by),
+                      const_cast<double*>(bz), stream);
+}
+
+int nbpp_add_clear_device(size_t n, double* ax, double* ay, double* az, double* bx, double* by,
+                          double* bz, void* stream) {
+    return add_arrays(true, n, ax, ay, az, bx, by, bz, stream);
 }
 
 int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz, const double* ax,

@@ -1880,14 +1880,15 @@ __global__ void k_kick(size_t n, double* __restrict__ vx, double* __restrict__ v
 }
 
 // a += b                                                          src/particles.cpp:362-364
+template <bool CLEAR>   // CLEAR: b is left holding zeros (the sums of the next evaluation start from them)
 __global__ void k_add(size_t n, double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
-                      const double* __restrict__ bx, const double* __restrict__ by,
-                      const double* __restrict__ bz) {
+                      double* __restrict__ bx, double* __restrict__ by, double* __restrict__ bz) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         ax[i] = __dadd_rn(ax[i], bx[i]);
         ay[i] = __dadd_rn(ay[i], by[i]);
         az[i] = __dadd_rn(az[i], bz[i]);
+        if constexpr (CLEAR) { bx[i] = 0.0; by[i] = 0.0; bz[i] = 0.0; }
     }
 }
 

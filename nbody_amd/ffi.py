@@ -22,6 +22,7 @@ EXPORTS = (
     "nbpp_accumulate", "nbpp_host_alloc", "nbpp_host_free", "nbpp_accumulate_device",
     "nbpp_accumulate_device_noalloc",
     "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device", "nbpp_add_device",
+    "nbpp_add_clear_device",
     "nbpp_max_accel_sq_device",
 )
 
@@ -104,6 +105,7 @@ class Library:
             C.c_int, C.c_int] + [_DP] * 3 + [C.c_void_p]
         L.nbpp_kick_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 3 + [C.c_void_p]
         L.nbpp_add_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_void_p]
+        L.nbpp_add_clear_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_void_p]
         L.nbpp_drift_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 2 + [C.c_void_p]
         L.nbpp_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
         self._inited = False
@@ -181,10 +183,11 @@ class Library:
             _dev(ax), _dev(ay), _dev(az), C.c_void_p(stream or 0)))
 
     # caller contract ---------------------------------------------------------------
-    def add_device(self, a, b, stream=None):
-        """a += b per component (nbpp_add_device)."""
-        self._check(self.lib.nbpp_add_device(a[0].numel(), _dev(a[0]), _dev(a[1]), _dev(a[2]),
-                                             _dev(b[0]), _dev(b[1]), _dev(b[2]), C.c_void_p(stream or 0)))
+    def add_device(self, a, b, stream=None, clear=False):
+        """a += b per component (nbpp_add_device); clear: b = 0 afterwards (nbpp_add_clear_device)."""
+        fn = self.lib.nbpp_add_clear_device if clear else self.lib.nbpp_add_device
+        self._check(fn(a[0].numel(), _dev(a[0]), _dev(a[1]), _dev(a[2]),
+                       _dev(b[0]), _dev(b[1]), _dev(b[2]), C.c_void_p(stream or 0)))
 
     def kick_device(self, v, a, dt, scale_factor, hubble, stream=None):
         self._check(self.lib.nbpp_kick_device(v[0].numel(), _dev(v[0]), _dev(v[1]), _dev(v[2]),

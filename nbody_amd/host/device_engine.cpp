@@ -61,7 +61,6 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
         hip_check(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&pp_stream_), hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pos_), hipEventDisableTiming), "hipEventCreate");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pp_), hipEventDisableTiming), "hipEventCreate");
-        hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_added_), hipEventDisableTiming), "hipEventCreate");
         for (double*& a : pp_acc_) hip_check(hipMalloc(reinterpret_cast<void**>(&a), sizeof(double) * n_), "hipMalloc");
     }
     const bool meshes = config_.USE_PM || config_.USE_HYDRO;
@@ -103,7 +102,6 @@ DeviceEngine::~DeviceEngine() {
         if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     if (ev_pos_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_pos_));
     if (ev_pp_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_pp_));
-    if (ev_added_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_added_));
     if (pp_stream_) (void)hipStreamDestroy(static_cast<hipStream_t>(pp_stream_));
     if (main_) (void)hipStreamDestroy(static_cast<hipStream_t>(main_));
     for (double* p : pp_acc_)
@@ -176,12 +174,9 @@ void DeviceEngine::compute_accelerations() {
                                           pp_acc_[2], pp_stream_));
         hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pp_), pps), "event");
         hip_check(hipStreamWaitEvent(ms, static_cast<hipEvent_t>(ev_pp_), 0), "wait");
-        nbpp_check(nbpp_add_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2], main_));
-        // the sums are cleared for the next evaluation as soon as they have been added, on their
-        // own stream, beside the kicks: not in front of the next short-range call
-        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_added_), ms), "event");
-        hip_check(hipStreamWaitEvent(pps, static_cast<hipEvent_t>(ev_added_), 0), "wait");
-        for (double* a : pp_acc_) hip_check(hipMemsetAsync(a, 0, sizeof(double) * n_, pps), "zero");
+        // added and cleared in one pass: the next evaluation (which waits for this cycle's drift,
+        // queued behind this kernel) finds zeros without a pass of its own in front of it
+        nbpp_check(nbpp_add_clear_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2], main_));
         pp_acc_zeroed_ = true;
     } else if (config_.USE_PP && n_total_ && ranks_ > 0) {                   // :254-258, over the ranks
         const nbpp_params p = config_.pp_params();

@@ -410,6 +410,11 @@ def test_add_device_is_one_rounding_per_component(lib):
     for c in range(3):
         assert np.array_equal(ta[c].cpu().numpy(), a[c] + b[c])
         assert np.array_equal(tb[c].cpu().numpy(), b[c])
+    lib.add_device(ta, tb, clear=True)     # nbpp_add_clear_device: the same sum, then b = 0
+    torch.cuda.synchronize()
+    for c in range(3):
+        assert np.array_equal(ta[c].cpu().numpy(), (a[c] + b[c]) + b[c])
+        assert not tb[c].cpu().numpy().any()
 
 
 def test_kick_drift_max_exact(lib, oracle):
