@@ -1458,18 +1458,20 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
         }
         const p3m_pool_vf dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
         const p3m_pool_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
-        const unsigned tag = static_cast<unsigned>(lane) << P3M_POOL_LANE_SHIFT;
+        const int left = je - j;        // candidates of this trip that belong to the run (may be <= 0)
+        const unsigned entry0 = (static_cast<unsigned>(lane) << P3M_POOL_LANE_SHIFT) | static_cast<unsigned>(j);
 #pragma unroll
         for (int u = 0; u < P3M_POOL_TRIP; ++u) {
-            const bool pass = (j + u < je) & !(r2[u] > bound);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            // two compares straight into lane masks, combined on the scalar side
+            const bool in_run = u < left, near = !(r2[u] > bound);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(in_run) & __builtin_amdgcn_ballot_w64(near);
             // the survivors of this slot go to consecutive ring entries in lane order
             const int at = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
                                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), static_cast<unsigned>(wp)));
             Entry entry;
             if constexpr (WIDE) entry = make_uint2(static_cast<unsigned>(lane), static_cast<unsigned>(j + u));
-            else entry = tag | static_cast<unsigned>(j + u);
-            if (pass) ring[at & (P3M_POOL_CAP - 1)] = entry;
+            else entry = entry0 + static_cast<unsigned>(u);
+            if (in_run & near) ring[at & (P3M_POOL_CAP - 1)] = entry;
             wp += __popcll(m);
             if (u % 4 == 3)       // at most 127 left + 4 * 64 new entries in a ring of 512
                 while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, 128);
