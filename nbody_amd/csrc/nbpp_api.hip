@@ -629,7 +629,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // target, occupancy measure below the pooled kernel's threshold): measured against
     // k_p3m_cells on jittered lattices, pair kernel alone, 0.125 / 0.131 ms at 64^3,
     // 0.673 / 0.711 at 128^3, 2.05 / 2.30 at 192^3, 4.67 / 5.00 at 256^3.
-    const bool sym = all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide &&
+    const bool table_fits = static_cast<unsigned long long>(ncell) <= START_TABLE_CHECKED_MAX_CELLS;
+    const bool sym = all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
                      n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
                      (g.opt_p3m_sym > 0 ||
                       (g.opt_p3m_sym == 0 && !g.opt_deterministic && lanes == 1 && occupancy < 6.0));
@@ -644,20 +645,17 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         g.stats.pair_launches = 1;
         return NBPP_OK;
     }
-    // one lane per target and particles that are not spread evenly: the survivors of the filter
-    // are pooled per wavefront and evaluated 64 at a time whatever target they belong to
-    // (k_p3m_pool), unless reproducible sums are asked for.  Measured, kernel time pooled against
-    // per lane: 256^3 jittered lattice (occupancy measure 2.6) 5.20 against 5.17 ms; the 128^3 run
-    // at a = 0.25 (2.9) 0.93 against 1.00 ms, at a = 0.33 (3.4) 1.07 against 1.22, at a = 0.40 (4.4)
-    // 1.23 against 1.47, at a = 0.51 (7.3) 1.54 against 1.97; 400 tight blobs 13.1 against 14.8 ms.
-    constexpr double POOL_FROM_OCCUPANCY = 2.7;
-    const bool pooled = lanes == 1 && (g.opt_p3m_pooled > 0 ||
-                                       (g.opt_p3m_pooled == 0 && !g.opt_deterministic &&
-                                        occupancy >= POOL_FROM_OCCUPANCY));
+    // one lane per target: the survivors of the filter are pooled per wavefront and evaluated 64
+    // at a time whatever target they belong to (k_p3m_pool), unless reproducible sums are asked
+    // for.  Measured, kernel time pooled against per lane: 256^3 jittered lattice (occupancy
+    // measure 2.6) 4.79 against 5.08 ms; the 128^3 run at a = 0.25 (2.9) 0.93 against 1.00 ms, at
+    // a = 0.33 (3.4) 1.07 against 1.22, at a = 0.40 (4.4) 1.23 against 1.47, at a = 0.51 (7.3) 1.40
+    // against 1.96; 400 tight blobs 12.5 against 14.8 ms.
+    const bool pooled = lanes == 1 && (g.opt_p3m_pooled > 0 || (g.opt_p3m_pooled == 0 && !g.opt_deterministic));
     g.stats.p3m_pooled = pooled ? 1 : 0;
     if (pooled) {
         // its ring entries keep the sorted position in 26 bits; beyond that the two-word form
-        const bool pool_wide = wide || n_entries + P3M_POOL_TRIP >= (1 << P3M_POOL_LANE_SHIFT);
+        const bool pool_wide = wide || !table_fits || n_entries + P3M_POOL_TRIP >= (1 << P3M_POOL_LANE_SHIFT);
         if (soft0) {
             if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<true, true>), grid_dim, wg_dim, 0, s, a);
             else hipLaunchKernelGGL((k_p3m_pool<true, false>), grid_dim, wg_dim, 0, s, a);

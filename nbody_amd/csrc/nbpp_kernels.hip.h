@@ -1055,6 +1055,31 @@ __device__ __forceinline__ int load_word(const int* base, int idx) {   // idx < 
     return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) +
                                          (static_cast<uint32_t>(idx) << 2));
 }
+// Row bounds through a range-checked buffer load: a lane without a row passes an offset past
+// the end and gets 0 in the destination register itself, with no select after the load, so the
+// value is not waited for before it is used a row later.  CHECKED = false (the ncell + 1 words
+// take 4 GiB or more): plain loads.
+template <bool CHECKED>
+struct StartTable {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const int* base;
+};
+template <bool CHECKED>
+__device__ __forceinline__ StartTable<CHECKED> make_start_table(const int* cell_start, const GhostGrid& g) {
+    const unsigned long long bytes = (1ull * g.np * g.np * g.np + 1ull) << 2;
+    return StartTable<CHECKED>{__builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(cell_start), 0,
+                                                                 CHECKED ? static_cast<uint32_t>(bytes) : 0u, 0x00020000),
+                               cell_start};
+}
+template <bool CHECKED>
+__device__ __forceinline__ int load_start(const StartTable<CHECKED>& t, int idx, bool has) {
+    if constexpr (CHECKED)
+        return static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, has ? static_cast<uint32_t>(idx) << 2 : 0xfffffffcu, 0, 0));
+    else
+        return has ? load_word(t.base, idx) : 0;
+}
+constexpr unsigned long long START_TABLE_CHECKED_MAX_CELLS = (0xfffffff0ull >> 2) - 1ull;   // cells whose table fits
+
 static_assert((P3M_QCAP & (P3M_QCAP - 1)) == 0 && P3M_DRAIN % P3M_DRAIN_UNROLL == 0 && P3M_DRAIN % 4 == 0 &&
               P3M_QCAP % P3M_DRAIN_UNROLL == 0 && P3M_DRAIN >= P3M_TRIP && (P3M_TRIP == 2 || P3M_TRIP == 4 || P3M_TRIP == 8),
               "ring sizes");
@@ -1132,7 +1157,7 @@ __device__ __forceinline__ bool row_window(const RowTrim& w, int ox, int oy, int
     const float dxm = ox > 0 ? static_cast<float>(ox) - w.tx : (ox < 0 ? w.tx - static_cast<float>(ox + 1) : 0.0f);
     const float dym = oy > 0 ? static_cast<float>(oy) - w.ty : (oy < 0 ? w.ty - static_cast<float>(oy + 1) : 0.0f);
     const float h2 = w.rc2 - dxm * dxm - dym * dym;
-    const float h = __builtin_sqrtf(fmaxf(h2, 0.0f)) + 1e-4f;
+    const float h = __builtin_amdgcn_sqrtf(fmaxf(h2, 0.0f)) + 1e-4f;   // v_sqrt_f32 as it is: 1 ulp, far inside the margin
     zlo = max(-R, static_cast<int>(floorf(w.tz - h)));
     zhi = min(R, static_cast<int>(floorf(w.tz + h)));
     return h2 >= 0.0f;
@@ -1423,12 +1448,13 @@ __global__ void __launch_bounds__(WG) k_p3m_pool(const P3MArgs a) {
     int j = 0, je = 0;
     int nj = 0, nje = 0;
     const RowTrim trim = make_row_trim(me, pcx, pcy, pcz, g, k);
+    const StartTable<!WIDE> starts = make_start_table<!WIDE>(a.cell_start, g);
     // the part of row (ox, oy) this target can reach; padding lanes copy the last target: their runs are empty
     auto request_row = [&](bool has) {
         int zlo, zhi;
         has = row_window(trim, ox - g.R, oy - g.R, g.R, zlo, zhi) && has;
-        nj = has ? load_word(a.cell_start, base + zlo) : 0;
-        nje = has ? load_word(a.cell_start, base + zhi + 1) : 0;
+        nj = load_start(starts, base + zlo, has);
+        nje = load_start(starts, base + zhi + 1, has);
     };
     request_row(live);
 #pragma unroll 1
@@ -1672,6 +1698,7 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
     const int span = 2 * g.R + 1;
     const int n_rows = g.R * span + g.R + 1;     // the own row, then every row after it in (x, y) order
+    const StartTable<true> starts = make_start_table<true>(a.cell_start, g);
     unsigned hits = 0;
     constexpr int DU = SYM_DU;
 
@@ -1740,8 +1767,8 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
             int zlo, zhi;                       // the part of the row this particle can reach
             const bool has = row_window(trim, ox, oy, g.R, zlo, zhi) && live && r < n_rows;
             const int base = ((pcx + ox) * g.np + (pcy + oy)) * g.np + pcz;
-            first = has ? load_word(a.cell_start, base + zlo) : 0;
-            last = has ? load_word(a.cell_start, base + zhi + 1) : 0;
+            first = load_start(starts, base + zlo, has);
+            last = load_start(starts, base + zhi + 1, has);
             if (r == 0) first = has ? p + 1 : 0;
             tg = ((rcx + ox) * CY + (rcy + oy)) << SYM_JBITS;
         };
