@@ -52,11 +52,11 @@ for name, n_side, make in sets:
             print(f"{name:28s} pair once: does not fit (fell back)", flush=True)
             continue
         rows.append({"set": name, "kernel": {-1: "k_p3m_cells", 1: "k_p3m_pool", 2: "k_p3m_sym"}[pooled],
-                     "kernel_ms": best["pair_kernel_ms"],
+                     "kernel_ms": best["pair_kernel_ms"], "binning_ms": best["prepare_ms"],
                      "pairs_accepted": best["pairs_accepted"], "cell_occupancy": best["cell_occupancy"],
                      "G_pairs_per_s": best["pairs_accepted"] / best["pair_kernel_ms"] * 1e-6})
         label = {-1: "per lane ", 1: "pooled   ", 2: "pair once"}[pooled]
-        print(f"{name:28s} {label}: kernel {best['pair_kernel_ms']:8.3f} ms, "
+        print(f"{name:28s} {label}: binning {best['prepare_ms']:6.3f} ms, kernel {best['pair_kernel_ms']:8.3f} ms, "
               f"{best['pairs_accepted']:.4g} accepted pairs, {rows[-1]['G_pairs_per_s']:.1f} G/s, "
               f"cell occupancy {best['cell_occupancy']:.2f}", flush=True)
     lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
