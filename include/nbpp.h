@@ -124,8 +124,9 @@ enum {
                                     members, reactions gathered per brick of cells in LDS and
                                     added to the outputs with fp64 atomics, when the particle
                                     set is even enough for a brick's neighbourhood to fit in
-                                    LDS and NBPP_OPT_DETERMINISTIC is off), 1 = whenever it
-                                    fits, -1 = never                                          */
+                                    LDS and NBPP_OPT_DETERMINISTIC is off; not tried in the call
+                                    after one that found the particles clustered,
+                                    cell_occupancy >= 6.5), 1 = whenever it fits, -1 = never   */
 };
 
 /*

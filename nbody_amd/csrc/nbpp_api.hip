@@ -138,6 +138,7 @@ struct Ctx : Work {
     Arena fixed;                      // the device's copy of the fixed workspace (nbpp_accumulate_device_noalloc)
     double* bounce = nullptr;         // page-locked host buffer the sums of nbpp_accumulate come back through
     size_t bounce_bytes = 0;
+    double last_occupancy = 0.0;   // clustering measure of the most recent P3M call
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
             opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0;
     nbpp_stats stats{};
@@ -525,7 +526,10 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         HIPCHK(hipMemsetAsync(occ, 0, 4 * sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_occupancy, dim3(static_cast<int>(std::min<long long>(256, cdiv(ncell, WG)))), dim3(WG), 0, s,
                            static_cast<int>(ncell), count, start, occ);
-        const bool sym_possible = all_targets && R <= SYM_MAXR && g.opt_p3m_sym >= 0;
+        // (not asked for by itself while the last call found the particles clustered: it would not be
+        // chosen, and its pre-pass costs 30-50 us)
+        const bool sym_possible = all_targets && R <= SYM_MAXR &&
+                                  (g.opt_p3m_sym > 0 || (g.opt_p3m_sym == 0 && g.last_occupancy < 6.5));
         if (sym_possible)
             hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(16LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
                                nbx, nby, nbz, occ + 2);
@@ -536,6 +540,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         if (n_entries > 0) occupancy = static_cast<double>(host[0]) / n_entries;
         if (sym_possible) region_max = host[2];
         g.stats.cell_occupancy = occupancy;
+        g.last_occupancy = occupancy;
     }
     if (n_entries < (grid.keep_len == nside ? n_src : n_tgt))
         return fail(NBPP_ERR_HIP, "binning lost particles (%d entries)", n_entries);
