@@ -153,6 +153,17 @@ void DeviceEngine::compute_accelerations() {
             hip_check(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(ev_[0]), static_cast<hipEvent_t>(ev_[1])), "event");
             pm_ms += ms;
         }
+        // The closing half kick of the gas (src/integrator.cpp:272-273) needs the mesh gradients
+        // only: queued here it runs beside the short-range force instead of behind it.  The
+        // particles' kick, which needs the sums, follows in step(); the two touch different
+        // arrays, so their order does not matter.
+        if (config_.USE_HYDRO && gas_kick_after_mesh_ > 0.0) {
+            const nbgas_params gp = config_.gas_params();
+            const nbgas_state gs = gas_state();
+            nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], gas_kick_after_mesh_,
+                                          cosmo.scale_factor, cosmo.hubble_param, main_));
+            gas_kick_after_mesh_ = 0.0;
+        }
     }
     if (!config_.USE_PM) {                                                   // :246-251
         for (int c = 6; c < 9; ++c)
@@ -273,9 +284,9 @@ void DeviceEngine::step() {
     const nbgas_params gp = config_.gas_params();
     const nbgas_state gs = gas_state();
     update_cosmology(cosmo, config_);                                                   // integrator.cpp:216
-    if (config_.USE_HYDRO)                                                              // :219-220
-        nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,
-                                      cosmo.hubble_param, main_));
+    // The particles first: the short-range force of this cycle starts on its own stream as soon as
+    // they have drifted.  The gas's opening half kick (:219-220) touches other arrays, so it may
+    // follow the drift instead of preceding the particles' kick.
     nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
                                 cosmo.scale_factor, cosmo.hubble_param, main_));      // :221
     nbpp_check(nbpp_drift_device(n_, dev_[0], dev_[1], dev_[2], dev_[3], dev_[4], dev_[5], dt,
@@ -284,6 +295,9 @@ void DeviceEngine::step() {
         hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pos_), ms), "event");
         pos_event_recorded_ = true;
     }
+    if (config_.USE_HYDRO)                                                              // :219-220
+        nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,
+                                      cosmo.hubble_param, main_));
     if (config_.USE_HYDRO) {                                                            // :227-230
         if (timed_) hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), ms), "event");
         nbgas_check(nbgas_hydro_step_device(&gp, &gs, dt, main_));
@@ -291,10 +305,8 @@ void DeviceEngine::step() {
     }
     cosmo.total_time += dt;                                                             // :233
     update_cosmology(cosmo, config_);                                                   // :234
+    gas_kick_after_mesh_ = config_.USE_HYDRO ? dt / 2.0 : 0.0;                          // :272-273, see there
     compute_accelerations();                                                            // :236-269
-    if (config_.USE_HYDRO)                                                              // :272-273
-        nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,
-                                      cosmo.hubble_param, main_));
     nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
                                 cosmo.scale_factor, cosmo.hubble_param, main_));      // :274
     ++cycle_count;
