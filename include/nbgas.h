@@ -61,6 +61,11 @@ int nbgas_hydro_step_device(const nbgas_params* p, const nbgas_state* s, double 
  * +inf when the largest signal speed is below 1e-9.  Blocking: *dt_out is a host double. */
 int nbgas_cfl_timestep_device(const nbgas_params* p, const nbgas_state* s, double* dt_out,
                               void* stream);
+/* The same in two halves, for a caller that has other work to queue while the maximum is being
+ * found: _enqueue_device queues the reduction and its read-back on `stream` and returns;
+ * _finish waits for that read-back and gives the time step.  One enqueue in flight at a time. */
+int nbgas_cfl_timestep_enqueue_device(const nbgas_params* p, const nbgas_state* s, void* stream);
+int nbgas_cfl_timestep_finish(const nbgas_params* p, double* dt_out);
 
 /* apply_gas_kick (src/integrator.cpp:134-166): primitives, then momentum += rho (g/a^3 - 2 H v) dt
  * and energy += v . (that source) dt.  gx, gy, gz: the mesh accelerations (libnbpm). */

@@ -37,6 +37,8 @@ struct Ctx {
     Buf scratch;     // five conserved meshes: the other side of the sweeps' ping-pong
     Buf blockmax;
     void* pinned = nullptr;   // 8 KiB of page-locked host memory for the CFL read-back
+    hipEvent_t cfl_done = nullptr;   // the read-back of nbgas_cfl_timestep_enqueue_device has landed
+    unsigned cfl_blocks = 0;         // partial maxima in flight (0: nothing enqueued)
 };
 Ctx g;
 std::mutex g_mu;
@@ -292,6 +294,9 @@ void nbgas_shutdown(void) {
     (void)hipDeviceSynchronize();
     g.scratch.release();
     g.blockmax.release();
+    if (g.cfl_done) (void)hipEventDestroy(g.cfl_done);
+    g.cfl_done = nullptr;
+    g.cfl_blocks = 0;
     if (g.pinned) (void)hipHostFree(g.pinned);
     g.pinned = nullptr;
     g.ready = false;
@@ -330,24 +335,40 @@ int nbgas_hydro_step_device(const nbgas_params* p, const nbgas_state* s, double 
     return NBGAS_OK;
 }
 
-int nbgas_cfl_timestep_device(const nbgas_params* p, const nbgas_state* s, double* dt_out, void* stream) {
+int nbgas_cfl_timestep_enqueue_device(const nbgas_params* p, const nbgas_state* s, void* stream) {
     ENTER();
     CHK(check(p, s));
-    if (!dt_out) return fail(NBGAS_ERR_ARG, "dt_out is NULL");
     const size_t total = static_cast<size_t>(p->mesh_size) * p->mesh_size * p->mesh_size;
     const unsigned blocks = std::min<unsigned>(cdiv(total, WG), 1024u);
     CHK(g.blockmax.ensure(sizeof(double) * blocks));
+    if (!g.cfl_done) HIPCHK(hipEventCreateWithFlags(&g.cfl_done, hipEventDisableTiming));
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_signal_max, dim3(blocks), dim3(WG), 0, st, total, p->gamma, *s, g.blockmax.as<double>());
     HIPCHK(hipGetLastError());
-    double* host = static_cast<double*>(g.pinned);   // 1024 doubles fit
-    HIPCHK(hipMemcpyAsync(host, g.blockmax.p, sizeof(double) * blocks, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpyAsync(g.pinned, g.blockmax.p, sizeof(double) * blocks, hipMemcpyDeviceToHost, st));   // 1024 doubles fit
+    HIPCHK(hipEventRecord(g.cfl_done, st));
+    g.cfl_blocks = blocks;
+    return NBGAS_OK;
+}
+
+int nbgas_cfl_timestep_finish(const nbgas_params* p, double* dt_out) {
+    ENTER();
+    if (!p || !dt_out) return fail(NBGAS_ERR_ARG, "NULL argument");
+    if (g.cfl_blocks == 0) return fail(NBGAS_ERR_ARG, "nbgas_cfl_timestep_enqueue_device has not been called");
+    HIPCHK(hipEventSynchronize(g.cfl_done));
+    const double* host = static_cast<const double*>(g.pinned);
     double m = host[0];
-    for (unsigned b = 1; b < blocks; ++b) m = (host[b] > m) ? host[b] : m;
+    for (unsigned b = 1; b < g.cfl_blocks; ++b) m = (host[b] > m) ? host[b] : m;
+    g.cfl_blocks = 0;
     if (m < 1e-9) *dt_out = std::numeric_limits<double>::infinity();       // src/gas.cpp:320
     else *dt_out = (p->cell_size / m) * p->cfl_safety_factor;              // :322
     return NBGAS_OK;
+}
+
+int nbgas_cfl_timestep_device(const nbgas_params* p, const nbgas_state* s, double* dt_out, void* stream) {
+    if (!dt_out) return fail(NBGAS_ERR_ARG, "dt_out is NULL");
+    const int rc = nbgas_cfl_timestep_enqueue_device(p, s, stream);
+    return rc != NBGAS_OK ? rc : nbgas_cfl_timestep_finish(p, dt_out);
 }
 
 int nbgas_kick_device(const nbgas_params* p, const nbgas_state* s, const double* gx, const double* gy,

@@ -351,7 +351,8 @@ GAS_LIB_PATH = os.environ.get("NBGAS_LIB") or os.path.join(HERE, "lib", "libnbga
 
 GAS_EXPORTS = (
     "nbgas_init", "nbgas_shutdown", "nbgas_last_error", "nbgas_update_primitives_device",
-    "nbgas_hydro_step_device", "nbgas_cfl_timestep_device", "nbgas_kick_device",
+    "nbgas_hydro_step_device", "nbgas_cfl_timestep_device", "nbgas_cfl_timestep_enqueue_device",
+    "nbgas_cfl_timestep_finish", "nbgas_kick_device",
     "nbgas_total_density_device", "nbgas_initialize_device",
 )
 
@@ -391,6 +392,8 @@ class GasLibrary:
         L.nbgas_update_primitives_device.argtypes = [P, S, C.c_void_p]
         L.nbgas_hydro_step_device.argtypes = [P, S, C.c_double, C.c_void_p]
         L.nbgas_cfl_timestep_device.argtypes = [P, S, C.POINTER(C.c_double), C.c_void_p]
+        L.nbgas_cfl_timestep_enqueue_device.argtypes = [P, S, C.c_void_p]
+        L.nbgas_cfl_timestep_finish.argtypes = [P, C.POINTER(C.c_double)]
         L.nbgas_kick_device.argtypes = [P, S] + [_DP] * 3 + [C.c_double] * 3 + [C.c_void_p]
         L.nbgas_total_density_device.argtypes = [P, S, _DP, _DP, C.c_void_p]
         L.nbgas_initialize_device.argtypes = [P, S] + [_DP] * 4 + [C.c_double] * 3 + [C.c_int, C.c_double,
@@ -431,6 +434,16 @@ class GasLibrary:
         out = C.c_double(0.0)
         self._check(self.lib.nbgas_cfl_timestep_device(C.byref(p), C.byref(s), C.byref(out),
                                                        C.c_void_p(stream or 0)))
+        return out.value
+
+    def cfl_timestep_enqueue_device(self, p, tensors, stream=None):
+        """First half of cfl_timestep_device: queues the reduction and its read-back."""
+        s = self.state(tensors)
+        self._check(self.lib.nbgas_cfl_timestep_enqueue_device(C.byref(p), C.byref(s), C.c_void_p(stream or 0)))
+
+    def cfl_timestep_finish(self, p):
+        out = C.c_double(0.0)
+        self._check(self.lib.nbgas_cfl_timestep_finish(C.byref(p), C.byref(out)))
         return out.value
 
     def kick_device(self, p, tensors, grav, dt, scale_factor, hubble, stream=None):

@@ -102,6 +102,8 @@ def test_three_steps_in_a_row_and_cfl(gaslib):
     for _ in range(3):
         dt = G.cfl_timestep(g, 1.0 / M, gamma, 0.4)
         assert gaslib.cfl_timestep_device(p, t) == pytest.approx(dt, rel=1e-13)
+        gaslib.cfl_timestep_enqueue_device(p, t)          # the same in two halves
+        assert gaslib.cfl_timestep_finish(p) == gaslib.cfl_timestep_device(p, t)
         G.hydro_step(g, dt, 1.0 / M, gamma)
         gaslib.hydro_step_device(p, t, dt)
     assert_state_close(t, g, tol=1e-12)
