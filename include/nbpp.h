@@ -242,6 +242,11 @@ int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n,
  *                       same single rounding as the reference's mesh += sum.
  * nbpp_add_clear_device a += b, then b = 0: the same, leaving the sums' arrays ready for the
  *                       next evaluation without a separate pass over them.
+ * nbpp_kick_drift_device       nbpp_kick_device(dt_kick) followed by nbpp_drift_device(dt_drift)
+ * nbpp_add_clear_kick_device   nbpp_add_clear_device followed by nbpp_kick_device(dt)
+ *                       in one pass over the particles each: the operations on every element and
+ *                       their order are those of the separate calls, so are the results, bit for
+ *                       bit (src/integrator.cpp:221-224 and :274 with the sum before it).
  */
 int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz,
                      const double* ax, const double* ay, const double* az,
@@ -255,6 +260,15 @@ int nbpp_add_device(size_t n, double* ax, double* ay, double* az,
                     const double* bx, const double* by, const double* bz, void* stream);
 int nbpp_add_clear_device(size_t n, double* ax, double* ay, double* az,
                           double* bx, double* by, double* bz, void* stream);
+int nbpp_kick_drift_device(size_t n, double* x, double* y, double* z,
+                           double* vx, double* vy, double* vz,
+                           const double* ax, const double* ay, const double* az,
+                           double dt_kick, double dt_drift, double scale_factor, double hubble,
+                           double domain_size, void* stream);
+int nbpp_add_clear_kick_device(size_t n, double* ax, double* ay, double* az,
+                               double* bx, double* by, double* bz,
+                               double* vx, double* vy, double* vz,
+                               double dt, double scale_factor, double hubble, void* stream);
 
 #ifdef __cplusplus
 }

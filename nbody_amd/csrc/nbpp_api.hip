@@ -1064,6 +1064,40 @@ int nbpp_drift_device(size_t n, double* x, double* y, double* z, const double* v
     return NBPP_OK;
 }
 
+int nbpp_kick_drift_device(size_t n, double* x, double* y, double* z, double* vx, double* vy, double* vz,
+                           const double* ax, const double* ay, const double* az, double dt_kick,
+                           double dt_drift, double scale_factor, double hubble, double domain_size,
+                           void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    if (n == 0) return NBPP_OK;
+    if (!x || !y || !z || !vx || !vy || !vz || !ax || !ay || !az) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    if (!(domain_size > 0.0)) return fail(NBPP_ERR_ARG, "domain_size must be positive");
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double a3 = scale_factor * scale_factor * scale_factor;  // src/integrator.cpp:169
+    const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
+    hipLaunchKernelGGL(k_kick_drift, dim3(blocks), dim3(WG), 0, s, n, x, y, z, vx, vy, vz, ax, ay, az,
+                       dt_kick / a3, dt_kick * 2.0 * hubble, dt_drift, domain_size, 1.0 / domain_size);
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
+int nbpp_add_clear_kick_device(size_t n, double* ax, double* ay, double* az, double* bx, double* by,
+                               double* bz, double* vx, double* vy, double* vz, double dt,
+                               double scale_factor, double hubble, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    if (n == 0) return NBPP_OK;
+    if (!ax || !ay || !az || !bx || !by || !bz || !vx || !vy || !vz) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double a3 = scale_factor * scale_factor * scale_factor;
+    const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
+    hipLaunchKernelGGL(k_add_clear_kick, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz, vx, vy, vz,
+                       dt / a3, dt * 2.0 * hubble);
+    HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
 int nbpp_max_accel_sq_device(size_t n, const double* ax, const double* ay, const double* az,
                              double* out_host, void* stream) {
     if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");

@@ -1937,6 +1937,44 @@ __global__ void k_drift(size_t n, double* __restrict__ x, double* __restrict__ y
     }
 }
 
+// k_kick then k_drift in one pass over the particles: the same operations on every element in
+// the same order, so the results are those of the two kernels bit for bit.
+__global__ void k_kick_drift(size_t n, double* __restrict__ x, double* __restrict__ y, double* __restrict__ z,
+                             double* __restrict__ vx, double* __restrict__ vy, double* __restrict__ vz,
+                             const double* __restrict__ ax, const double* __restrict__ ay,
+                             const double* __restrict__ az, double dt_over_a3, double dt_2H, double dt,
+                             double L, double inv_L) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double ux = vx[i] + (__dmul_rn(ax[i], dt_over_a3) - __dmul_rn(vx[i], dt_2H));
+        const double uy = vy[i] + (__dmul_rn(ay[i], dt_over_a3) - __dmul_rn(vy[i], dt_2H));
+        const double uz = vz[i] + (__dmul_rn(az[i], dt_over_a3) - __dmul_rn(vz[i], dt_2H));
+        vx[i] = ux; vy[i] = uy; vz[i] = uz;
+        const double nx = __dadd_rn(x[i], __dmul_rn(ux, dt));
+        const double ny = __dadd_rn(y[i], __dmul_rn(uy, dt));
+        const double nz = __dadd_rn(z[i], __dmul_rn(uz, dt));
+        x[i] = __dsub_rn(nx, __dmul_rn(L, floor(__dmul_rn(nx, inv_L))));
+        y[i] = __dsub_rn(ny, __dmul_rn(L, floor(__dmul_rn(ny, inv_L))));
+        z[i] = __dsub_rn(nz, __dmul_rn(L, floor(__dmul_rn(nz, inv_L))));
+    }
+}
+
+// k_add<true> then k_kick in one pass: a += b, b = 0, v kicked with the new a.
+__global__ void k_add_clear_kick(size_t n, double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
+                                 double* __restrict__ bx, double* __restrict__ by, double* __restrict__ bz,
+                                 double* __restrict__ vx, double* __restrict__ vy, double* __restrict__ vz,
+                                 double dt_over_a3, double dt_2H) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double sx = __dadd_rn(ax[i], bx[i]), sy = __dadd_rn(ay[i], by[i]), sz = __dadd_rn(az[i], bz[i]);
+        ax[i] = sx; ay[i] = sy; az[i] = sz;
+        bx[i] = 0.0; by[i] = 0.0; bz[i] = 0.0;
+        vx[i] = vx[i] + (__dmul_rn(sx, dt_over_a3) - __dmul_rn(vx[i], dt_2H));
+        vy[i] = vy[i] + (__dmul_rn(sy, dt_over_a3) - __dmul_rn(vy[i], dt_2H));
+        vz[i] = vz[i] + (__dmul_rn(sz, dt_over_a3) - __dmul_rn(vz[i], dt_2H));
+    }
+}
+
 // max_i (ax^2 + ay^2 + az^2), per-block partial maxima              src/integrator.cpp:200-213
 __global__ void __launch_bounds__(WG) k_max_accel_sq(size_t n, const double* __restrict__ ax,
                                                      const double* __restrict__ ay,

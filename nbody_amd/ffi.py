@@ -22,7 +22,7 @@ EXPORTS = (
     "nbpp_accumulate", "nbpp_host_alloc", "nbpp_host_free", "nbpp_accumulate_device",
     "nbpp_accumulate_device_noalloc",
     "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device", "nbpp_add_device",
-    "nbpp_add_clear_device",
+    "nbpp_add_clear_device", "nbpp_kick_drift_device", "nbpp_add_clear_kick_device",
     "nbpp_max_accel_sq_device",
 )
 
@@ -106,6 +106,8 @@ class Library:
         L.nbpp_kick_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 3 + [C.c_void_p]
         L.nbpp_add_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_void_p]
         L.nbpp_add_clear_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_void_p]
+        L.nbpp_kick_drift_device.argtypes = [C.c_size_t] + [_DP] * 9 + [C.c_double] * 5 + [C.c_void_p]
+        L.nbpp_add_clear_kick_device.argtypes = [C.c_size_t] + [_DP] * 9 + [C.c_double] * 3 + [C.c_void_p]
         L.nbpp_drift_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 2 + [C.c_void_p]
         L.nbpp_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
         self._inited = False
@@ -188,6 +190,17 @@ class Library:
         fn = self.lib.nbpp_add_clear_device if clear else self.lib.nbpp_add_device
         self._check(fn(a[0].numel(), _dev(a[0]), _dev(a[1]), _dev(a[2]),
                        _dev(b[0]), _dev(b[1]), _dev(b[2]), C.c_void_p(stream or 0)))
+
+    def kick_drift_device(self, x, v, a, dt_kick, dt_drift, scale_factor, hubble, domain_size, stream=None):
+        """kick_device(dt_kick) then drift_device(dt_drift) in one pass (nbpp_kick_drift_device)."""
+        self._check(self.lib.nbpp_kick_drift_device(
+            x[0].numel(), *[_dev(t) for t in (*x, *v, *a)], dt_kick, dt_drift, scale_factor, hubble, domain_size,
+            C.c_void_p(stream or 0)))
+
+    def add_clear_kick_device(self, a, b, v, dt, scale_factor, hubble, stream=None):
+        """add_device(clear=True) then kick_device(dt) in one pass (nbpp_add_clear_kick_device)."""
+        self._check(self.lib.nbpp_add_clear_kick_device(
+            a[0].numel(), *[_dev(t) for t in (*a, *b, *v)], dt, scale_factor, hubble, C.c_void_p(stream or 0)))
 
     def kick_device(self, v, a, dt, scale_factor, hubble, stream=None):
         self._check(self.lib.nbpp_kick_device(v[0].numel(), _dev(v[0]), _dev(v[1]), _dev(v[2]),

@@ -193,7 +193,14 @@ void DeviceEngine::compute_accelerations() {
         hip_check(hipStreamWaitEvent(ms, static_cast<hipEvent_t>(ev_pp_), 0), "wait");
         // added and cleared in one pass: the next evaluation (which waits for this cycle's drift,
         // queued behind this kernel) finds zeros without a pass of its own in front of it
-        nbpp_check(nbpp_add_clear_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2], main_));
+        if (kick_after_forces_ > 0.0) {   // ... and the particles' closing half kick (:274) in the same pass
+            nbpp_check(nbpp_add_clear_kick_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2],
+                                                  dev_[3], dev_[4], dev_[5], kick_after_forces_, cosmo.scale_factor,
+                                                  cosmo.hubble_param, main_));
+            kick_fused_ = true;
+        } else {
+            nbpp_check(nbpp_add_clear_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2], main_));
+        }
         pp_acc_zeroed_ = true;
     } else if (config_.USE_PP && n_total_ && ranks_ > 0) {                   // :254-258, over the ranks
         const nbpp_params p = config_.pp_params();
@@ -295,10 +302,9 @@ void DeviceEngine::step() {
     // The particles first: the short-range force of this cycle starts on its own stream as soon as
     // they have drifted.  The gas's opening half kick (:219-220) touches other arrays, so it may
     // follow the drift instead of preceding the particles' kick.
-    nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
-                                cosmo.scale_factor, cosmo.hubble_param, main_));      // :221
-    nbpp_check(nbpp_drift_device(n_, dev_[0], dev_[1], dev_[2], dev_[3], dev_[4], dev_[5], dt,
-                                 config_.DOMAIN_SIZE, main_));                        // :224
+    nbpp_check(nbpp_kick_drift_device(n_, dev_[0], dev_[1], dev_[2], dev_[3], dev_[4], dev_[5], dev_[6], dev_[7],
+                                      dev_[8], dt / 2.0, dt, cosmo.scale_factor, cosmo.hubble_param,
+                                      config_.DOMAIN_SIZE, main_));                   // :221 and :224 in one pass
     if (pp_stream_ && overlap_forces && !timed_) {
         hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pos_), ms), "event");
         pos_event_recorded_ = true;
@@ -314,9 +320,15 @@ void DeviceEngine::step() {
     cosmo.total_time += dt;                                                             // :233
     update_cosmology(cosmo, config_);                                                   // :234
     gas_kick_after_mesh_ = config_.USE_HYDRO ? dt / 2.0 : 0.0;                          // :272-273, see there
+    // :274, in one pass with the sum of mesh and short-range force where the cycle has one (standing
+    // particles are kicked with the zeroed accelerations, after compute_accelerations() has cleared them)
+    kick_after_forces_ = config_.STANDING_PARTICLES ? 0.0 : dt / 2.0;
+    kick_fused_ = false;
     compute_accelerations();                                                            // :236-269
-    nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
-                                cosmo.scale_factor, cosmo.hubble_param, main_));      // :274
+    kick_after_forces_ = 0.0;
+    if (!kick_fused_)
+        nbpp_check(nbpp_kick_device(n_, dev_[3], dev_[4], dev_[5], dev_[6], dev_[7], dev_[8], dt / 2.0,
+                                    cosmo.scale_factor, cosmo.hubble_param, main_));  // :274
     ++cycle_count;
     if (timed_) ++timed_steps;
     if (config_.USE_HYDRO && timed_) {

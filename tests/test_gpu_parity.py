@@ -440,6 +440,37 @@ def test_kick_drift_max_exact(lib, oracle):
     assert lib.max_accel_sq_device(tiny) == 1e-9
 
 
+def test_fused_kick_drift_and_add_clear_kick_equal_the_separate_calls(lib, oracle):
+    """nbpp_kick_drift_device and nbpp_add_clear_kick_device: one pass over the particles each,
+    the same operations per element in the same order as the separate calls (and as the oracle's
+    kick and drift, src/integrator.cpp:168-198): equal bit for bit."""
+    import torch
+    rng = np.random.default_rng(12)
+    n = 70001
+    v = [rng.standard_normal(n) for _ in range(3)]
+    a = [rng.standard_normal(n) * 1e-2 for _ in range(3)]
+    b = [rng.standard_normal(n) * 1e-3 for _ in range(3)]
+    x = [rng.random(n) * 2.5 for _ in range(3)]
+    dt, sc, H, L = 3.1e-3, 0.05, 120.3, 2.5
+    tx, tv, ta = _t(x), _t(v), _t(a)
+    lib.kick_drift_device(tx, tv, ta, dt / 2, dt, sc, H, L)
+    torch.cuda.synchronize()
+    oracle.kick(v, a, dt / 2, sc, H)
+    oracle.drift(x, v, dt, L)
+    for c in range(3):
+        assert np.array_equal(tv[c].cpu().numpy(), v[c])
+        assert np.array_equal(tx[c].cpu().numpy(), x[c])
+    tb = _t(b)
+    lib.add_clear_kick_device(ta, tb, tv, dt / 2, sc, H)
+    torch.cuda.synchronize()
+    s = [a[c] + b[c] for c in range(3)]
+    oracle.kick(v, s, dt / 2, sc, H)
+    for c in range(3):
+        assert np.array_equal(ta[c].cpu().numpy(), s[c])
+        assert not tb[c].cpu().numpy().any()
+        assert np.array_equal(tv[c].cpu().numpy(), v[c])
+
+
 # --------------------------------------------------------------------------------------
 # full-size properties (the 128^3 headline size, sampled)
 # --------------------------------------------------------------------------------------
