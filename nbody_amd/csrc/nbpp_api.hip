@@ -112,14 +112,13 @@ struct Work {
     Sorted src, tgt;
     Buf part[3];                      // per-slice partial sums
     Buf host_in[4], host_acc[3];      // staging for the host-pointer entry point
-    Buf canon[3];                     // P3M: positions brought into [0, L)
     Buf blockmax, counter, massinfo;
     Buf biglist;                      // cells too full for the one-thread sort: two lists of count, ids
     Buf ghostcode;                    // P3M: image code of every sorted entry
     template <class F> void each(F f) {
         for (Buf* b : {&count, &blocksum, &part[0], &part[1], &part[2], &host_in[0],
                        &host_in[1], &host_in[2], &host_in[3], &host_acc[0], &host_acc[1],
-                       &host_acc[2], &canon[0], &canon[1], &canon[2], &blockmax, &counter, &massinfo, &biglist, &ghostcode})
+                       &host_acc[2], &blockmax, &counter, &massinfo, &biglist, &ghostcode})
             f(*b);
         src.each(f);
         tgt.each(f);
@@ -498,9 +497,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         }
     }
 
-    // 1. positions into [0, L), histogram over real + ghost cells, offsets
-    for (Buf& b : g.canon) CHK(b.ensure(sizeof(double) * n_src));
-    double *cx = g.canon[0].as<double>(), *cy = g.canon[1].as<double>(), *cz = g.canon[2].as<double>();
+    // 1. histogram over real + ghost cells, offsets
     CHK(g.count.ensure(sizeof(int) * (ncell + 1)));
     CHK(g.src.start.ensure(sizeof(int) * (ncell + 1)));
     int* count = g.count.as<int>();
@@ -508,7 +505,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int) * (ncell + 1), s));
     CHK(g.tgt.rank.ensure(sizeof(int) * n_src));
     int* rank = g.tgt.rank.as<int>();
-    hipLaunchKernelGGL(k_ghost_count, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z, grid, cx, cy, cz,
+    hipLaunchKernelGGL(k_ghost_count, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z, grid,
                        count, rank);
     CHK(exclusive_scan(static_cast<int>(ncell + 1), count, start, s));
     // the one host read-back of the call: real + ghost entries and the clustering measure of
@@ -531,7 +528,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         const bool sym_possible = all_targets && R <= SYM_MAXR &&
                                   (g.opt_p3m_sym > 0 || (g.opt_p3m_sym == 0 && g.last_occupancy < 6.5));
         if (sym_possible)
-            hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(16LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
+            hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(1LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
                                nbx, nby, nbz, occ + 2);
         unsigned long long* host = static_cast<unsigned long long*>(g.pinned);
         HIPCHK(hipMemcpyAsync(host, occ, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -545,7 +542,49 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     if (n_entries < (grid.keep_len == nside ? n_src : n_tgt))
         return fail(NBPP_ERR_HIP, "binning lost particles (%d entries)", n_entries);
 
-    // 2. scatter, canonical order inside each cell, records
+    // Which pair kernel will run is known now (everything it depends on has been read back), and
+    // the binning below depends on it: only k_p3m_cells needs the members of a cell in a fixed
+    // order.
+    const bool wide = n_entries >= (1 << 27);   // 32-byte records beyond 32-bit byte offsets
+    // lanes per target: more of them while the launch is too small to occupy the GPU.  Lanes of
+    // one target walk different rows, which costs the coalescing that neighbouring targets on the
+    // same row have, so on evenly spread particles one lane per target wins from about 2^16
+    // targets up (measured at 32^3 to 128^3: 32^3 best with 2-4 lanes, 48^3 and larger with 1).
+    // Clustered sets have a few very long targets and want more lanes for the same count
+    // (32^3 at a = 0.5 to 1: 8 lanes), hence the occupancy factor.
+    int lanes = 1;
+    const double enough = 65536.0 * std::min(std::max(occupancy, 1.0), 16.0);
+    while (lanes < 8 && static_cast<double>(n_tgt) * lanes < enough) lanes *= 2;
+    if (g.opt_p3m_lanes == 1 || g.opt_p3m_lanes == 2 || g.opt_p3m_lanes == 4 || g.opt_p3m_lanes == 8 ||
+        g.opt_p3m_lanes == 16)
+        lanes = static_cast<int>(g.opt_p3m_lanes);
+    // every unordered pair once, reactions gathered per brick in LDS (k_p3m_sym): a full
+    // evaluation whose fullest brick region fits, sums not asked to be reproducible, outputs in
+    // ordinary device memory (fp64 atomics).  Chosen by itself for large, even sets (one lane per
+    // target, occupancy measure below the pooled kernel's threshold): measured against
+    // k_p3m_cells on jittered lattices, pair kernel alone, 0.125 / 0.131 ms at 64^3,
+    // 0.673 / 0.711 at 128^3, 2.05 / 2.30 at 192^3, 4.67 / 5.00 at 256^3.
+    const bool table_fits = static_cast<unsigned long long>(ncell) <= START_TABLE_CHECKED_MAX_CELLS;
+    const bool sym = all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
+                     n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
+                     (g.opt_p3m_sym > 0 ||
+                      (g.opt_p3m_sym == 0 && !g.opt_deterministic && lanes == 1 && occupancy < 6.0));
+    // one lane per target: the survivors of the filter are pooled per wavefront and evaluated 64
+    // at a time whatever target they belong to (k_p3m_pool), unless reproducible sums are asked
+    // for.  Measured, kernel time pooled against per lane: 256^3 jittered lattice (occupancy
+    // measure 2.6) 4.79 against 5.08 ms; the 128^3 run at a = 0.25 (2.9) 0.93 against 1.00 ms, at
+    // a = 0.33 (3.4) 1.07 against 1.22, at a = 0.40 (4.4) 1.23 against 1.47, at a = 0.51 (7.3) 1.40
+    // against 1.96; 400 tight blobs 12.5 against 14.8 ms.
+    const bool pooled = lanes == 1 && (g.opt_p3m_pooled > 0 || (g.opt_p3m_pooled == 0 && !g.opt_deterministic));
+
+    // 2. scatter and records.  k_p3m_cells promises sums that repeat from run to run: the members
+    // of every cell are put into ascending original order before their records are gathered.  The
+    // other two kernels add in whatever order the hardware takes their atomics, so for them the
+    // order the scatter's own atomics produced will do (three kernels and two fills less: 0.15 of
+    // 0.38 ms of binning on the clustered 128^3 set, 0.1 of 0.9 ms on the 256^3 lattice).  (Writing
+    // the records from the scatter itself, without a gather, was measured too: the scattered
+    // 4-byte stores cost more than the gather's reads, 0.87 against 0.81 ms at 256^3.)
+    const bool fixed_order = !(sym || pooled);
     CHK(g.src.order.ensure(sizeof(int) * n_entries));
     CHK(g.src.x.ensure(sizeof(double4) * n_entries));  // AoS records live in the x buffer
     int* entries = g.src.order.as<int>();
@@ -558,14 +597,16 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     float* fx = g.src.y.as<float>();
     float* fy = fx + f_stride;
     float* fz = fy + f_stride;
-    hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, cx, cy, cz, grid,
+    hipLaunchKernelGGL(k_ghost_scatter, dim3(cdiv(n_src, WG)), dim3(WG), 0, s, n_src, x, y, z, grid,
                        start, count, rank, entries, codes);
-    CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));   // scratch here, target flags / slots below
-    CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
-    CHK(canonical_order(static_cast<int>(ncell), n_entries, start, entries, g.src.cell.as<int>(),
-                        g.src.rank.as<int>(), s));
+    if (fixed_order) {
+        CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));   // scratch here, target flags / slots below
+        CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));
+        CHK(canonical_order(static_cast<int>(ncell), n_entries, start, entries, g.src.cell.as<int>(),
+                            g.src.rank.as<int>(), s));
+    }
     hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
-                       cx, cy, cz, m, p->G, p->domain_size, rec, fx, fy, fz);
+                       x, y, z, m, p->G, p->domain_size, rec, fx, fy, fz);
 
     // 3. list of targets in sorted order
     CHK(g.tgt.order.ensure(sizeof(int) * n_tgt));
@@ -613,32 +654,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     a.ax = ax; a.ay = ay; a.az = az;
     a.accepted = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
     a.k = k;
-    const bool wide = n_entries >= (1 << 27);   // 32-byte records beyond 32-bit byte offsets
-    // lanes per target: more of them while the launch is too small to occupy the GPU.  Lanes of
-    // one target walk different rows, which costs the coalescing that neighbouring targets on the
-    // same row have, so on evenly spread particles one lane per target wins from about 2^16
-    // targets up (measured at 32^3 to 128^3: 32^3 best with 2-4 lanes, 48^3 and larger with 1).
-    // Clustered sets have a few very long targets and want more lanes for the same count
-    // (32^3 at a = 0.5 to 1: 8 lanes), hence the occupancy factor.
-    int lanes = 1;
-    const double enough = 65536.0 * std::min(std::max(occupancy, 1.0), 16.0);
-    while (lanes < 8 && static_cast<double>(n_tgt) * lanes < enough) lanes *= 2;
-    if (g.opt_p3m_lanes == 1 || g.opt_p3m_lanes == 2 || g.opt_p3m_lanes == 4 || g.opt_p3m_lanes == 8 ||
-        g.opt_p3m_lanes == 16)
-        lanes = static_cast<int>(g.opt_p3m_lanes);
     const dim3 grid_dim(cdiv(static_cast<long long>(n_tgt) * lanes, WG)), wg_dim(WG);
     const bool soft0 = p->soft_sq == 0.0;
-    // every unordered pair once, reactions gathered per brick in LDS (k_p3m_sym): a full
-    // evaluation whose fullest brick region fits, sums not asked to be reproducible, outputs in
-    // ordinary device memory (fp64 atomics).  Chosen by itself for large, even sets (one lane per
-    // target, occupancy measure below the pooled kernel's threshold): measured against
-    // k_p3m_cells on jittered lattices, pair kernel alone, 0.125 / 0.131 ms at 64^3,
-    // 0.673 / 0.711 at 128^3, 2.05 / 2.30 at 192^3, 4.67 / 5.00 at 256^3.
-    const bool table_fits = static_cast<unsigned long long>(ncell) <= START_TABLE_CHECKED_MAX_CELLS;
-    const bool sym = all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
-                     n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
-                     (g.opt_p3m_sym > 0 ||
-                      (g.opt_p3m_sym == 0 && !g.opt_deterministic && lanes == 1 && occupancy < 6.0));
     g.stats.p3m_pooled = 0;
     if (sym) {
         const dim3 bricks(nbx * nby * nbz);
@@ -650,13 +667,6 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         g.stats.pair_launches = 1;
         return NBPP_OK;
     }
-    // one lane per target: the survivors of the filter are pooled per wavefront and evaluated 64
-    // at a time whatever target they belong to (k_p3m_pool), unless reproducible sums are asked
-    // for.  Measured, kernel time pooled against per lane: 256^3 jittered lattice (occupancy
-    // measure 2.6) 4.79 against 5.08 ms; the 128^3 run at a = 0.25 (2.9) 0.93 against 1.00 ms, at
-    // a = 0.33 (3.4) 1.07 against 1.22, at a = 0.40 (4.4) 1.23 against 1.47, at a = 0.51 (7.3) 1.40
-    // against 1.96; 400 tight blobs 12.5 against 14.8 ms.
-    const bool pooled = lanes == 1 && (g.opt_p3m_pooled > 0 || (g.opt_p3m_pooled == 0 && !g.opt_deterministic));
     g.stats.p3m_pooled = pooled ? 1 : 0;
     if (pooled) {
         // its ring entries keep the sorted position in 26 bits; beyond that the two-word form

@@ -801,18 +801,16 @@ __device__ __forceinline__ void for_each_image(double x, double y, double z, con
                   static_cast<unsigned>(code[0][ix] | (code[1][iy] << 2) | (code[2][iz] << 4)));
 }
 
-// Brings the positions into [0, L) (kept in cx, cy, cz for the passes after this one) and counts
-// every image's cell.  What the counter of its own cell held when a particle arrived is kept as
-// the particle's rank there, so that k_ghost_scatter can place the real images without a second
-// round of atomics.
+// Counts every image's cell, the positions brought into [0, L) first (every pass after this one
+// does the same on the fly: two compares per coordinate instead of three more arrays).  What the
+// counter of its own cell held when a particle arrived is kept as the particle's rank there, so
+// that k_ghost_scatter can place the real images without a second round of atomics.
 __global__ void k_ghost_count(int n, const double* __restrict__ x, const double* __restrict__ y,
-                              const double* __restrict__ z, GhostGrid g, double* __restrict__ cx,
-                              double* __restrict__ cy, double* __restrict__ cz, int* __restrict__ count,
+                              const double* __restrict__ z, GhostGrid g, int* __restrict__ count,
                               int* __restrict__ rank) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double px = canonical(x[i], g.L), py = canonical(y[i], g.L), pz = canonical(z[i], g.L);
-    cx[i] = px; cy[i] = py; cz[i] = pz;
     if (!x_cell_kept(g, bin_coord(px, g.scale, g.nside))) return;
     for_each_image(px, py, pz, g, [&](int cell, unsigned code) {
         if (code == 0u) rank[i] = atomicAdd(&count[cell], 1);
@@ -853,8 +851,9 @@ __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const doubl
                                 int* __restrict__ entries, uint8_t* __restrict__ codes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (!x_cell_kept(g, bin_coord(x[i], g.scale, g.nside))) return;   // the same test as k_ghost_count's
-    for_each_image(x[i], y[i], z[i], g, [&](int cell, unsigned code) {
+    const double px = canonical(x[i], g.L), py = canonical(y[i], g.L), pz = canonical(z[i], g.L);
+    if (!x_cell_kept(g, bin_coord(px, g.scale, g.nside))) return;   // the same test as k_ghost_count's
+    for_each_image(px, py, pz, g, [&](int cell, unsigned code) {
         const int slot = start[cell] + (code == 0u ? rank[i] : atomicSub(&fill[cell], 1) - 1);
         entries[slot] = i;
         codes[slot] = static_cast<uint8_t>(code);
@@ -874,8 +873,9 @@ __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
     if (p >= n_entries) return;
     const int i = entries[p];
     const unsigned code = codes[p];
-    const double4 r = make_double4(x[i] + image_shift(code & 3u, L), y[i] + image_shift((code >> 2) & 3u, L),
-                                   z[i] + image_shift((code >> 4) & 3u, L), G * m[i]);
+    const double4 r = make_double4(canonical(x[i], L) + image_shift(code & 3u, L),
+                                   canonical(y[i], L) + image_shift((code >> 2) & 3u, L),
+                                   canonical(z[i], L) + image_shift((code >> 4) & 3u, L), G * m[i]);
     rec[p] = r;
     // single-precision copies for the cutoff pre-filter of k_p3m_cells, one array per axis
     fx[p] = static_cast<float>(r.x);
@@ -1553,7 +1553,6 @@ constexpr int SYM_DU = 4;           // record fetches in flight per lane while d
 constexpr int SYM_MAXR = 3;         // search radius in cells the tables are sized for
 constexpr int SYM_MAXCOL = (SYM_BX + SYM_MAXR) * (SYM_BY + 2 * SYM_MAXR);
 constexpr int SYM_JBITS = 25;       // ring entries: region column << 25 | sorted position
-static_assert(SYM_BY + 2 * SYM_MAXR <= 16, "k_sym_region_max gives a brick 16 lanes, one per y column of its region");
 
 // S (f_pp - f_pm) of src/particles.cpp:330-355 for r^2 <= cutoff_sq (without G m and d).
 template <bool SOFT0>
@@ -1581,24 +1580,22 @@ __device__ __forceinline__ double p3m_factor(double r2, const PairConsts& k) {
 // one does not fit SYM_CAP (a clustered set).
 __global__ void k_sym_region_max(GhostGrid g, const int* __restrict__ cell_start, int nbx, int nby, int nbz,
                                  unsigned long long* __restrict__ out) {
-    // 16 lanes per brick, one per y column of the region (SYM_BY + 2 SYM_MAXR <= 16), each over the region's x
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int brick = gt >> 4, ry = gt & 15;
+    // one thread per brick, bz fastest: neighbouring threads read neighbouring words of the same columns
+    const int brick = blockIdx.x * blockDim.x + threadIdx.x;
     int total = 0;
-    if (brick < nbx * nby * nbz && ry < SYM_BY + 2 * g.R) {
+    if (brick < nbx * nby * nbz) {
         const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
         const int x0 = g.R + bx * SYM_BX, y0 = g.R + by * SYM_BY, z0 = g.R + bz * SYM_BZ;
         const int zlo = z0 - g.R, zhi = min(z0 + SYM_BZ, g.R + g.nside) + g.R;
-        const int py = y0 - g.R + ry;
-        for (int rx = 0; rx < SYM_BX + g.R; ++rx) {
-            const int px = x0 + rx;
-            if (px >= g.np || py >= g.np) continue;
-            const int col = (px * g.np + py) * g.np;
-            total += cell_start[col + zhi] - cell_start[col + zlo];
-        }
+        for (int rx = 0; rx < SYM_BX + g.R; ++rx)
+            for (int ry = 0; ry < SYM_BY + 2 * g.R; ++ry) {
+                const int px = x0 + rx, py = y0 - g.R + ry;
+                if (px >= g.np || py >= g.np) continue;
+                const int col = (px * g.np + py) * g.np;
+                total += cell_start[col + zhi] - cell_start[col + zlo];
+            }
     }
-    for (int d = 1; d < 16; d <<= 1) total += __shfl_xor(total, d, 64);
-    for (int d = 16; d < 64; d <<= 1) total = max(total, __shfl_xor(total, d, 64));
+    for (int d = 1; d < 64; d <<= 1) total = max(total, __shfl_xor(total, d, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, static_cast<unsigned long long>(total));
 }
 
