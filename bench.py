@@ -138,6 +138,56 @@ def extra_p3m256(lib, ffi, torch, dev, stream, steps=6, warmup=2):
                          "flops_per_accepted_pair": FLOPS_PER_PAIR_P3M}}
 
 
+def extra_kdk32(lib, ffi, torch, dev, stream, steps=200, warmup=20):
+    """BASELINE config 1 on the GPU: PP direct summation, 32^3 particles from the Zel'dovich set of
+    the CPU leg (cpu_config1_kdk_step), whole KDK steps through the device entry points - kick and
+    drift, zeroed accelerations, full force evaluation, max |a|^2 read back (the caller contract of
+    src/integrator.cpp:236-269), closing kick."""
+    from nbody_amd import Config
+    import datasets
+    n_side = 32
+    n = n_side ** 3
+    config = Config(MESH_SIZE=31, N_PER_SIDE=n_side, USE_PM=False)
+    p = config.pp_params()
+    x = [torch.from_numpy(np.ascontiguousarray(c).copy()).to(dev) for c in datasets.zeldovich(n_side)]
+    v = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(3)]
+    a = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(3)]
+    mass = torch.full((n,), config.DM_PARTICLE_MASS, dtype=torch.float64, device=dev)
+    for k in (ffi.OPT_TARGETS_PER_LANE, ffi.OPT_FORCE_KERNEL, ffi.OPT_DETERMINISTIC):
+        lib.set_option(k, 0)
+    dt = config.FIXED_DT
+    lib.accumulate_device(p, *x, mass, *a, stream=stream)
+
+    def kdk():
+        lib.kick_drift_device(x, v, a, dt / 2.0, dt, 1.0, 0.0, config.DOMAIN_SIZE, stream=stream)
+        for c in a:
+            c.zero_()
+        lib.accumulate_device(p, *x, mass, *a, stream=stream)
+        lib.max_accel_sq_device(a, stream=stream)
+        lib.kick_device(v, a, dt / 2.0, 1.0, 0.0, stream=stream)
+
+    for _ in range(warmup):
+        kdk()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        kdk()
+        kernel_ms.append(lib.stats()["pair_kernel_ms"])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pairs = float(n) * float(n - 1)
+    k_ms = float(np.mean(kernel_ms))
+    return {"workload": "PP direct summation, 32^3 particles (Zel'dovich), whole KDK steps (BASELINE config 1 on the GPU)",
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+            "value": pairs * steps / elapsed / 1e9, "unit": "Ginter/s", "pairs_per_step": pairs,
+            "kernel_ms": k_ms,
+            "roofline": {"bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "achieved": pairs * FLOPS_PER_PAIR_DIRECT / (k_ms * 1e-3) / 1e12,
+                         "frac": pairs * FLOPS_PER_PAIR_DIRECT / (k_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "flops_per_interaction": FLOPS_PER_PAIR_DIRECT}}
+
+
 def extra_step128(cycles=100):
     """BASELINE config 5 under the same clock: the product's own C++ engine (a child process) runs
     tools/configs/p3m_hydro_128.ini for `cycles` KDK cycles, state resident in HBM.  Two runs:
@@ -474,6 +524,10 @@ def main():
             except Exception as e:   # the headline line must still be printed
                 extra["p3m256"] = {"error": repr(e)}
             torch.cuda.empty_cache()
+            try:
+                extra["kdk32"] = extra_kdk32(lib, ffi, torch, dev, stream)
+            except Exception as e:
+                extra["kdk32"] = {"error": repr(e)}
             try:
                 extra["step128"] = extra_step128()
             except Exception as e:

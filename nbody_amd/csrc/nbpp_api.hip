@@ -138,6 +138,12 @@ struct Ctx : Work {
     double* bounce = nullptr;         // page-locked host buffer the sums of nbpp_accumulate come back through
     size_t bounce_bytes = 0;
     double last_occupancy = 0.0;   // clustering measure of the most recent P3M call
+    // The pair-once kernel's pre-pass (k_sym_region_max) is not asked for in the calls that follow
+    // one whose fullest brick region did not fit, while the particle count and the search grid stay
+    // the same (a run clusters further, it does not spread out again): it is tried again every
+    // SYM_RETRY_CALLS calls.  The pre-pass sits in front of the call's one read-back.
+    int sym_skip_left = 0;
+    int sym_skip_n = 0, sym_skip_nside = 0;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
             opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0;
     nbpp_stats stats{};
@@ -525,17 +531,48 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
                            static_cast<int>(ncell), count, start, occ);
         // (not asked for by itself while the last call found the particles clustered: it would not be
         // chosen, and its pre-pass costs 30-50 us)
-        const bool sym_possible = all_targets && R <= SYM_MAXR &&
+        if (g.sym_skip_n != n_src || g.sym_skip_nside != nside) g.sym_skip_left = 0;
+        const bool sym_rested = g.opt_p3m_sym == 0 && g.sym_skip_left > 0;
+        if (sym_rested) --g.sym_skip_left;
+        const bool sym_possible = all_targets && R <= SYM_MAXR && !sym_rested &&
                                   (g.opt_p3m_sym > 0 || (g.opt_p3m_sym == 0 && g.last_occupancy < 6.5));
         if (sym_possible)
             hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(1LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
                                nbx, nby, nbz, occ + 2);
         unsigned long long* host = static_cast<unsigned long long*>(g.pinned);
         HIPCHK(hipMemcpyAsync(host, occ, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipEventRecord(g.ev[3], s));
+        // Work that needs nothing of what is read back is queued behind the copy, so the GPU has
+        // something to do while the host wakes up, decides and launches the rest: when every
+        // particle is a target the list of targets is the real entries in sorted order, one
+        // contiguous piece per column of the grid, and follows from the cell offsets alone.
+        if (all_targets && n_tgt > 0) {
+            CHK(g.tgt.order.ensure(sizeof(int) * n_tgt));
+            const int ncol = grid.np * grid.np;
+            CHK(g.src.cell.ensure(sizeof(int) * (ncol + 1)));
+            CHK(g.src.rank.ensure(sizeof(int) * (ncol + 1)));
+            int* col_count = g.src.cell.as<int>();
+            int* col_start = g.src.rank.as<int>();
+            if (ncol <= COLUMN_STARTS_SMALL_MAX) {
+                hipLaunchKernelGGL(k_column_starts_small, dim3(1), dim3(1024), 0, s, grid, start, col_start);
+            } else {
+                hipLaunchKernelGGL(k_column_counts, dim3(cdiv(ncol + 1, WG)), dim3(WG), 0, s, grid, start, col_count);
+                CHK(exclusive_scan(ncol + 1, col_count, col_start, s));
+            }
+            hipLaunchKernelGGL(k_column_targets, dim3(std::min(ncol, 65536)), dim3(WG), 0, s, grid, start, col_start,
+                               g.tgt.order.as<int>());
+        }
+        HIPCHK(hipEventSynchronize(g.ev[3]));
         n_entries = static_cast<int>(host[1]);
         if (n_entries > 0) occupancy = static_cast<double>(host[0]) / n_entries;
-        if (sym_possible) region_max = host[2];
+        if (sym_possible) {
+            region_max = host[2];
+            if (region_max > static_cast<unsigned long long>(SYM_CAP)) {
+                g.sym_skip_left = SYM_RETRY_CALLS - 1;
+                g.sym_skip_n = n_src;
+                g.sym_skip_nside = nside;
+            }
+        }
         g.stats.cell_occupancy = occupancy;
         g.last_occupancy = occupancy;
     }
@@ -608,25 +645,10 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
                        x, y, z, m, p->G, p->domain_size, rec, fx, fy, fz);
 
-    // 3. list of targets in sorted order
+    // 3. list of targets in sorted order (every particle a target: built in front of the read-back, above)
     CHK(g.tgt.order.ensure(sizeof(int) * n_tgt));
     int* tlist = g.tgt.order.as<int>();
-    if (all_targets) {
-        // every real entry: one contiguous piece per column of the grid
-        const int ncol = grid.np * grid.np;
-        CHK(g.src.cell.ensure(sizeof(int) * (ncol + 1)));
-        CHK(g.src.rank.ensure(sizeof(int) * (ncol + 1)));
-        int* col_count = g.src.cell.as<int>();
-        int* col_start = g.src.rank.as<int>();
-        if (ncol <= 16384) {
-            hipLaunchKernelGGL(k_column_starts_small, dim3(1), dim3(1024), 0, s, grid, start, col_start);
-        } else {
-            hipLaunchKernelGGL(k_column_counts, dim3(cdiv(ncol + 1, WG)), dim3(WG), 0, s, grid, start, col_count);
-            CHK(exclusive_scan(ncol + 1, col_count, col_start, s));
-        }
-        hipLaunchKernelGGL(k_column_targets, dim3(std::min(ncol, 65536)), dim3(WG), 0, s, grid, start, col_start,
-                           tlist);
-    } else {
+    if (!all_targets) {
         // a slice of the particles: flag the real entries in it and compact
         CHK(g.src.cell.ensure(sizeof(int) * (n_entries + 1)));
         CHK(g.src.rank.ensure(sizeof(int) * (n_entries + 1)));

@@ -920,38 +920,47 @@ __global__ void k_column_counts(GhostGrid g, const int* __restrict__ cell_start,
 }
 
 // The two steps above (counts, exclusive scan into col_start[0 .. np^2]) in one launch of one
-// workgroup of 1024 threads, for grids of up to a few thousand columns, where four launches cost
-// more than the work.
+// workgroup of 1024 threads, for grids of up to COLUMN_STARTS_SMALL_MAX columns, where four launches
+// cost more than the work.  A thread owns COLS consecutive columns and requests all their bounds
+// before it uses any, so the kernel waits for memory once (walking the columns 1024 at a time, one
+// dependent pair of loads per round, took 46 us at 11 000 columns and three times that beside
+// other kernels).
+constexpr int COLUMN_STARTS_SMALL_COLS = 17;
+constexpr int COLUMN_STARTS_SMALL_MAX = 1024 * COLUMN_STARTS_SMALL_COLS - 1;   // entry ncol is the total
 __global__ void __launch_bounds__(1024) k_column_starts_small(GhostGrid g, const int* __restrict__ cell_start,
                                                               int* __restrict__ col_start) {
+    constexpr int COLS = COLUMN_STARTS_SMALL_COLS;
     __shared__ int wave_total[16];
     const int ncol = g.np * g.np;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int carry = 0;
-    for (int base = 0; base <= ncol; base += 1024) {      // entry ncol is the total
-        const int col = base + threadIdx.x;
-        int c = 0;
-        if (col < ncol) {
-            const int X = col / g.np, Y = col - X * g.np;
-            if (X >= g.R && X < g.np - g.R && Y >= g.R && Y < g.np - g.R)
-                c = cell_start[col * g.np + g.np - g.R] - cell_start[col * g.np + g.R];
-        }
-        int inc = c;
+    const int first = threadIdx.x * COLS;
+    int lo[COLS], hi[COLS];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        if (lane == 63) wave_total[wave] = inc;
-        __syncthreads();
-        int before = 0, total = 0;
-        for (int w = 0; w < 16; ++w) {
-            before += w < wave ? wave_total[w] : 0;
-            total += wave_total[w];
-        }
-        if (col <= ncol) col_start[col] = carry + before + inc - c;
-        carry += total;
-        __syncthreads();
+    for (int k = 0; k < COLS; ++k) {
+        const int col = first + k;
+        const int X = col / g.np, Y = col - X * g.np;
+        const bool real = col < ncol && X >= g.R && X < g.np - g.R && Y >= g.R && Y < g.np - g.R;
+        lo[k] = real ? cell_start[col * g.np + g.R] : 0;
+        hi[k] = real ? cell_start[col * g.np + g.np - g.R] : 0;
+    }
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) mine += hi[k] - lo[k];
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_total[wave] = inc;
+    __syncthreads();
+    int at = inc - mine;
+    for (int w = 0; w < wave; ++w) at += wave_total[w];
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) {
+        const int col = first + k;
+        if (col <= ncol) col_start[col] = at;
+        at += hi[k] - lo[k];
     }
 }
 
@@ -1551,6 +1560,7 @@ constexpr bool SYM_PREFETCH = false;   // request trip i + 1's coordinates befor
                                        // (256^3: 4.67 ms against 4.81 with the prefetch and two fetches)
 constexpr int SYM_DU = 4;           // record fetches in flight per lane while draining
 constexpr int SYM_MAXR = 3;         // search radius in cells the tables are sized for
+constexpr int SYM_RETRY_CALLS = 16; // calls between two tries of the pre-pass once a brick region did not fit
 constexpr int SYM_MAXCOL = (SYM_BX + SYM_MAXR) * (SYM_BY + 2 * SYM_MAXR);
 constexpr int SYM_JBITS = 25;       // ring entries: region column << 25 | sorted position
 

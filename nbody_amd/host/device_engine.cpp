@@ -58,6 +58,8 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
     // (not with several ranks: the collectives of one communicator must be issued in one order,
     // which two streams do not give)
     if (config_.USE_PM && config_.USE_PP && n_ && ranks_ <= 1) {
+        // (a higher or a lower priority for this stream was measured: 1.61 and 1.60 ms per cycle at 128^3
+        // against 1.58 with equal priorities)
         hip_check(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&pp_stream_), hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pos_), hipEventDisableTiming), "hipEventCreate");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pp_), hipEventDisableTiming), "hipEventCreate");
@@ -128,6 +130,29 @@ void DeviceEngine::deposit_density() {
     if (ranks_ > 1) nbmg_check(nbmg_allreduce_sum_device(cells_, mesh_[0], main_));
 }
 
+// The overlapped short-range force: queued on its own stream, into sums of its own, as soon as
+// the positions of the cycle are final.  Its binning reads one count back, so the call blocks the
+// host for a few tens of microseconds; everything the main stream has to do in this cycle (gas,
+// mesh) is therefore queued AFTER this call, while the pair kernel runs.  Queued the other way
+// round, the pair kernel - the longest item of the cycle - started a third of a millisecond late
+// at 128^3, behind the host's two dozen launches.  false: not on this cycle (timed, no mesh force,
+// no second stream), the force phase then runs in order on the main stream.
+bool DeviceEngine::launch_short_range() {
+    const bool overlap = overlap_forces && !timed_ && pp_stream_ && pos_event_recorded_ && config_.USE_PM &&
+                         config_.USE_PP && n_ && ranks_ <= 1;
+    if (!overlap) return false;
+    hipStream_t pps = static_cast<hipStream_t>(pp_stream_);
+    const nbpp_params p = config_.pp_params();
+    hip_check(hipStreamWaitEvent(pps, static_cast<hipEvent_t>(ev_pos_), 0), "wait");
+    if (!pp_acc_zeroed_)
+        for (double* a : pp_acc_) hip_check(hipMemsetAsync(a, 0, sizeof(double) * n_, pps), "zero");
+    nbpp_check(nbpp_set_option(NBPP_OPT_TIMING, 0));
+    nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_, pp_acc_[0], pp_acc_[1],
+                                      pp_acc_[2], pp_stream_));
+    hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pp_), pps), "event");
+    return true;
+}
+
 void DeviceEngine::compute_accelerations() {
     hipStream_t ms = static_cast<hipStream_t>(main_);
     if (config_.USE_PM || config_.USE_HYDRO) {                               // :239-245
@@ -176,20 +201,10 @@ void DeviceEngine::compute_accelerations() {
             hip_check(hipMemsetAsync(dev_[c], 0, sizeof(double) * n_, ms), "zero acc");
         hip_check(hipStreamSynchronize(ms), "sync");
     }
-    const bool overlap = overlap_forces && !timed_ && pp_stream_ && pos_event_recorded_ && config_.USE_PM &&
-                         config_.USE_PP && n_;
-    if (overlap) {
-        // everything above is queued on the main stream and not waited for; the short-range force
-        // starts on its own stream as soon as the drift has finished
-        hipStream_t pps = static_cast<hipStream_t>(pp_stream_);
-        const nbpp_params p = config_.pp_params();
-        hip_check(hipStreamWaitEvent(pps, static_cast<hipEvent_t>(ev_pos_), 0), "wait");
-        if (!pp_acc_zeroed_)
-            for (double* a : pp_acc_) hip_check(hipMemsetAsync(a, 0, sizeof(double) * n_, pps), "zero");
-        nbpp_check(nbpp_set_option(NBPP_OPT_TIMING, 0));
-        nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_, pp_acc_[0], pp_acc_[1],
-                                          pp_acc_[2], pp_stream_));
-        hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pp_), pps), "event");
+    if (pp_launched_ || launch_short_range()) {
+        // the short-range force has been running on its own stream since the drift (step()) or has
+        // been started just now (initial force phase); the main stream waits for its sums
+        pp_launched_ = false;
         hip_check(hipStreamWaitEvent(ms, static_cast<hipEvent_t>(ev_pp_), 0), "wait");
         // added and cleared in one pass: the next evaluation (which waits for this cycle's drift,
         // queued behind this kernel) finds zeros without a pass of its own in front of it
@@ -308,6 +323,7 @@ void DeviceEngine::step() {
     if (pp_stream_ && overlap_forces && !timed_) {
         hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pos_), ms), "event");
         pos_event_recorded_ = true;
+        pp_launched_ = launch_short_range();   // before anything else of the cycle is queued
     }
     if (config_.USE_HYDRO)                                                              // :219-220
         nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], dt / 2.0, cosmo.scale_factor,

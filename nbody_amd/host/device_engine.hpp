@@ -79,6 +79,7 @@ class DeviceEngine {
    private:
     void compute_accelerations();        // src/integrator.cpp:236-269
     void deposit_density();
+    bool launch_short_range();           // the overlapped short-range force, on its own stream
     double next_timestep();              // src/engine.cpp:16-22, :47-51
     nbgas_state gas_state() const;
     Config config_;
@@ -105,6 +106,7 @@ class DeviceEngine {
     bool cfl_in_flight_ = false;         // the gas's CFL limit has been queued (nbgas_cfl_timestep_enqueue_device)
     bool pp_acc_zeroed_ = false;         // pp_acc_ holds zeros for the next overlapped evaluation
     bool pos_event_recorded_ = false;
+    bool pp_launched_ = false;           // step() has started this cycle's short-range force already
     double* pp_acc_[3] = {};             // short-range sums of the overlapped path
 };
 
