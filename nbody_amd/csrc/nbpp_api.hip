@@ -676,7 +676,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     a.ax = ax; a.ay = ay; a.az = az;
     a.accepted = g.opt_timing ? g.counter.as<unsigned long long>() : nullptr;
     a.k = k;
-    const dim3 grid_dim(cdiv(static_cast<long long>(n_tgt) * lanes, WG)), wg_dim(WG);
+    const dim3 grid_dim(cdiv(static_cast<long long>(n_tgt) * lanes, P3M_CELLS_WG)), wg_dim(P3M_CELLS_WG);
     const bool soft0 = p->soft_sq == 0.0;
     g.stats.p3m_pooled = 0;
     if (sym) {
@@ -693,12 +693,13 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     if (pooled) {
         // its ring entries keep the sorted position in 26 bits; beyond that the two-word form
         const bool pool_wide = wide || !table_fits || n_entries + P3M_POOL_TRIP >= (1 << P3M_POOL_LANE_SHIFT);
+        const dim3 pool_grid(cdiv(n_tgt, P3M_POOL_WG)), pool_wg(P3M_POOL_WG);
         if (soft0) {
-            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<true, true>), grid_dim, wg_dim, 0, s, a);
-            else hipLaunchKernelGGL((k_p3m_pool<true, false>), grid_dim, wg_dim, 0, s, a);
+            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<true, true>), pool_grid, pool_wg, 0, s, a);
+            else hipLaunchKernelGGL((k_p3m_pool<true, false>), pool_grid, pool_wg, 0, s, a);
         } else {
-            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<false, true>), grid_dim, wg_dim, 0, s, a);
-            else hipLaunchKernelGGL((k_p3m_pool<false, false>), grid_dim, wg_dim, 0, s, a);
+            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<false, true>), pool_grid, pool_wg, 0, s, a);
+            else hipLaunchKernelGGL((k_p3m_pool<false, false>), pool_grid, pool_wg, 0, s, a);
         }
         HIPCHK(hipGetLastError());
         g.stats.pairs_evaluated = 0;
