@@ -119,7 +119,7 @@ enum {
                                     at a time, sums added with LDS fp64 atomics, unless
                                     NBPP_OPT_DETERMINISTIC is set), 1 = always, -1 = never (every
                                     lane evaluates its own survivors, bitwise reproducible)  */
-    NBPP_OPT_P3M_PAIR_ONCE = 10  /* P3M cell kernel, all particles as targets: 0 = automatic
+    NBPP_OPT_P3M_PAIR_ONCE = 10, /* P3M cell kernel, all particles as targets: 0 = automatic
                                     (evaluate every unordered pair once and apply it to both
                                     members, reactions gathered per brick of cells in LDS and
                                     added to the outputs with fp64 atomics, when the particle
@@ -127,6 +127,13 @@ enum {
                                     LDS and NBPP_OPT_DETERMINISTIC is off; not tried in the call
                                     after one that found the particles clustered,
                                     cell_occupancy >= 6.5), 1 = whenever it fits, -1 = never   */
+    NBPP_OPT_P3M_POOL_WORKGROUP = 11 /* threads per workgroup of the pooled P3M kernel: 0 = 64, else
+                                    64, 128 or 256.  Its wavefronts work independently, and alone
+                                    on the GPU the kernel is 4-8 % faster with one wavefront per
+                                    workgroup; a caller that runs other kernels beside it on a
+                                    second stream should ask for 256, or single wavefront slots
+                                    are refilled by this kernel before a larger workgroup of the
+                                    other stream ever fits                                       */
 };
 
 /*

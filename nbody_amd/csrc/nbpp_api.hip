@@ -145,7 +145,7 @@ struct Ctx : Work {
     int sym_skip_left = 0;
     int sym_skip_n = 0, sym_skip_nside = 0;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0;
+            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0, opt_pool_wg = 0;
     nbpp_stats stats{};
 };
 
@@ -693,14 +693,20 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     if (pooled) {
         // its ring entries keep the sorted position in 26 bits; beyond that the two-word form
         const bool pool_wide = wide || !table_fits || n_entries + P3M_POOL_TRIP >= (1 << P3M_POOL_LANE_SHIFT);
-        const dim3 pool_grid(cdiv(n_tgt, P3M_POOL_WG)), pool_wg(P3M_POOL_WG);
+        const int pwg = g.opt_pool_wg ? static_cast<int>(g.opt_pool_wg) : 64;
+        const dim3 pool_grid(cdiv(n_tgt, pwg)), pool_wg(pwg);
+#define NBPP_LAUNCH_POOL(S0, W)                                                                         \
+    switch (pwg) {                                                                                      \
+        case 64: hipLaunchKernelGGL((k_p3m_pool<S0, W, 64>), pool_grid, pool_wg, 0, s, a); break;       \
+        case 128: hipLaunchKernelGGL((k_p3m_pool<S0, W, 128>), pool_grid, pool_wg, 0, s, a); break;     \
+        default: hipLaunchKernelGGL((k_p3m_pool<S0, W, 256>), pool_grid, pool_wg, 0, s, a); break;      \
+    }
         if (soft0) {
-            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<true, true>), pool_grid, pool_wg, 0, s, a);
-            else hipLaunchKernelGGL((k_p3m_pool<true, false>), pool_grid, pool_wg, 0, s, a);
+            if (pool_wide) { NBPP_LAUNCH_POOL(true, true) } else { NBPP_LAUNCH_POOL(true, false) }
         } else {
-            if (pool_wide) hipLaunchKernelGGL((k_p3m_pool<false, true>), pool_grid, pool_wg, 0, s, a);
-            else hipLaunchKernelGGL((k_p3m_pool<false, false>), pool_grid, pool_wg, 0, s, a);
+            if (pool_wide) { NBPP_LAUNCH_POOL(false, true) } else { NBPP_LAUNCH_POOL(false, false) }
         }
+#undef NBPP_LAUNCH_POOL
         HIPCHK(hipGetLastError());
         g.stats.pairs_evaluated = 0;
         g.stats.pair_launches = 1;
@@ -867,6 +873,11 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_P3M_LANES_PER_TARGET: g.opt_p3m_lanes = value; return NBPP_OK;
         case NBPP_OPT_P3M_POOLED_DRAIN: g.opt_p3m_pooled = value; return NBPP_OK;
         case NBPP_OPT_P3M_PAIR_ONCE: g.opt_p3m_sym = value; return NBPP_OK;
+        case NBPP_OPT_P3M_POOL_WORKGROUP:
+            if (value != 0 && value != 64 && value != 128 && value != 256)
+                return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_POOL_WORKGROUP takes 0, 64, 128 or 256");
+            g.opt_pool_wg = value;
+            return NBPP_OK;
         default: return fail(NBPP_ERR_ARG, "unknown option key %d", key);
     }
 }

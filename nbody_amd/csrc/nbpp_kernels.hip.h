@@ -1364,37 +1364,34 @@ __global__ void __launch_bounds__(P3M_CELLS_WG) k_p3m_cells(const P3MArgs a) {
 constexpr int P3M_POOL_CAP = 512;   // pairs per wavefront ring (power of 2): < 128 left by a drain + 4 * 64 from half a trip
 constexpr int P3M_POOL_TRIP = 8;    // candidates a lane tests per trip: the runs of a clustered set are long
                                     // (16: 120 registers, 4 waves/SIMD, slower on every set: a = 0.51 1.66 against 1.54 ms)
-// Threads per workgroup of k_p3m_pool.  Its wavefronts work independently (a ring, a target table and
-// sums per wavefront, no workgroup barrier), so any multiple of 64 will do.  Run by itself the kernel
-// is fastest with one wavefront per workgroup, whose slot on the CU is free again as soon as that
-// wavefront is done (64 / 128 / 256 threads: the 128^3 run at a = 0.51 1.29 / 1.29 / 1.40 ms, at
-// a = 0.21 0.746 / 0.756 / 0.773, 400 blobs 11.9 / 12.2 / 12.4 ms, the 256^3 lattice 4.77 / 4.73 /
-// 4.74).  Inside the whole step, where the mesh and gas kernels run beside it on another stream, it
-// is the other way round: single wavefront slots are refilled by this kernel before a four-wavefront
-// workgroup of the other stream ever fits, the mesh chain starves and the cycle takes 1.69 ms with 64
-// or 128 threads against 1.57 with 256 (128^3 particles + 128^3 gas mesh).  The step decides.
-#ifndef NBPP_POOL_WG
-#define NBPP_POOL_WG 256
-#endif
-constexpr int P3M_POOL_WG = NBPP_POOL_WG;
+// Threads per workgroup of k_p3m_pool: the template parameter PWG.  Its wavefronts work
+// independently (a ring, a target table and sums per wavefront, no workgroup barrier), so any
+// multiple of 64 will do.  Run by itself the kernel is fastest with one wavefront per workgroup,
+// whose slot on the CU is free again as soon as that wavefront is done (64 / 128 / 256 threads: the
+// 128^3 run at a = 0.51 1.29 / 1.29 / 1.40 ms, at a = 0.21 0.746 / 0.756 / 0.773, 400 blobs 11.9 /
+// 12.2 / 12.4 ms, the 256^3 lattice 4.77 / 4.73 / 4.74).  Inside a whole step, where mesh and gas
+// kernels run beside it on another stream, it is the other way round: single wavefront slots are
+// refilled by this kernel before a four-wavefront workgroup of the other stream ever fits, the
+// mesh chain starves and the cycle takes 1.69 ms with 64 or 128 threads against 1.57 with 256
+// (128^3 particles + 128^3 gas mesh).  Hence NBPP_OPT_P3M_POOL_WORKGROUP.
 constexpr int P3M_POOL_LANE_SHIFT = 26;   // ring entry = target lane << 26 | sorted position of the source (< 2^26)
 typedef float p3m_pool_vf __attribute__((ext_vector_type(P3M_POOL_TRIP)));
 
-template <bool SOFT0, bool WIDE>
-__global__ void __launch_bounds__(P3M_POOL_WG) k_p3m_pool(const P3MArgs a) {
+template <bool SOFT0, bool WIDE, int PWG>
+__global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
     // ring entries: target lane << 26 | sorted position of the source; {lane, position} when positions need more bits
     using Entry = std::conditional_t<WIDE, uint2, unsigned>;
-    __shared__ Entry pool[P3M_POOL_WG / 64][P3M_POOL_CAP];
-    __shared__ double2 txy[P3M_POOL_WG];                      // target x, y
-    __shared__ double tz[P3M_POOL_WG];                        // target z
-    __shared__ double tsum[3][P3M_POOL_WG];                   // the targets' sums
+    __shared__ Entry pool[PWG / 64][P3M_POOL_CAP];
+    __shared__ double2 txy[PWG];                      // target x, y
+    __shared__ double tz[PWG];                        // target z
+    __shared__ double tsum[3][PWG];                   // the targets' sums
     const int b = static_cast<int>(blockIdx.x);      // XCD-aware order of the pieces: see k_p3m_cells
-    constexpr int RUN = P3M_XCD_RUN * (WG / P3M_POOL_WG);   // the same stretch of the target list per XCD
+    constexpr int RUN = P3M_XCD_RUN * (WG / PWG);   // the same stretch of the target list per XCD
     const int group = b / (8 * RUN);
     const int in_group = b - group * (8 * RUN);
     const bool whole = (group + 1) * (8 * RUN) <= static_cast<int>(gridDim.x);
     const int piece = whole ? group * (8 * RUN) + (in_group % 8) * RUN + in_group / 8 : b;
-    const int t = piece * P3M_POOL_WG + threadIdx.x;
+    const int t = piece * PWG + threadIdx.x;
     const bool live = t < a.n_tgt;
     const int p = a.tlist[live ? t : a.n_tgt - 1];
     const double4 me = a.rec[p];

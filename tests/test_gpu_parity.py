@@ -917,6 +917,36 @@ def test_p3m_pooled_drain_equals_per_lane_drain(lib, oracle, name, n_side):
     assert normalised_error([a[:n_tgt] for a in out[1]], want, floor) < TOL
 
 
+@pytest.mark.parametrize("threads", [64, 128, 256])
+def test_p3m_pooled_kernel_workgroup_sizes(lib, oracle, threads):
+    """NBPP_OPT_P3M_POOL_WORKGROUP: the pooled kernel with one, two and four wavefronts per
+    workgroup (ragged target count, so the last workgroup is partly padding): the same exact
+    accepted-pair count as the oracle, sums within the parity bar; other values are refused."""
+    n_side = 36
+    n = n_side ** 3 - 37
+    pos = [c[:n].copy() for c in datasets.jittered_lattice(n_side, jitter=0.9)]
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True).pp_params()
+    try:
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 1)
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, -1)
+        lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, 1)
+        lib.set_option(ffi.OPT_P3M_POOL_WORKGROUP, threads)
+        got = gpu_acc(lib, p, pos, m)
+        st = lib.stats()
+        with pytest.raises(ffi.NbppError):
+            lib.set_option(ffi.OPT_P3M_POOL_WORKGROUP, 96)
+    finally:
+        for k in (ffi.OPT_P3M_LANES_PER_TARGET, ffi.OPT_P3M_PAIR_ONCE, ffi.OPT_P3M_POOLED_DRAIN,
+                  ffi.OPT_P3M_POOL_WORKGROUP):
+            lib.set_option(k, 0)
+    assert st["p3m_pooled"] == 1
+    assert st["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
+    n_tgt = 2048
+    want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=O.EXACT_CELLS)
+    assert normalised_error([a[:n_tgt] for a in got], want, pair_force_scale(p, m, n) * 1e-3) < TOL
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_p3m_kernels_agree_on_random_configurations(lib, oracle, seed):
     """The three P3M cell kernels (per-lane rings, reproducible; pooled survivors, eight
