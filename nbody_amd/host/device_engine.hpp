@@ -106,6 +106,7 @@ class DeviceEngine {
     bool cfl_in_flight_ = false;         // the gas's CFL limit has been queued (nbgas_cfl_timestep_enqueue_device)
     bool pp_acc_zeroed_ = false;         // pp_acc_ holds zeros for the next overlapped evaluation
     bool pos_event_recorded_ = false;
+    double last_occupancy_ = 0.0;        // clustering measure of the last short-range call (nbpp_stats)
     bool pp_launched_ = false;           // step() has started this cycle's short-range force already
     double* pp_acc_[3] = {};             // short-range sums of the overlapped path
 };
