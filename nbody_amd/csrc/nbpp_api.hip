@@ -534,8 +534,11 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         if (g.sym_skip_n != n_src || g.sym_skip_nside != nside) g.sym_skip_left = 0;
         const bool sym_rested = g.opt_p3m_sym == 0 && g.sym_skip_left > 0;
         if (sym_rested) --g.sym_skip_left;
+        // (nor by itself below 2^16 targets, which always get several lanes each: see `lanes` below)
         const bool sym_possible = all_targets && R <= SYM_MAXR && !sym_rested &&
-                                  (g.opt_p3m_sym > 0 || (g.opt_p3m_sym == 0 && g.last_occupancy < 6.5));
+                                  (g.opt_p3m_sym > 0 ||
+                                   (g.opt_p3m_sym == 0 && g.last_occupancy < 6.5 && n_tgt >= 65536 && !g.opt_deterministic &&
+                                    (g.opt_p3m_lanes == 0 || g.opt_p3m_lanes == 1)));
         if (sym_possible)
             hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(1LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
                                nbx, nby, nbz, occ + 2);
