@@ -254,6 +254,10 @@ int nbpp_accumulate_pairs_device(const nbpp_params* p, size_t n,
  *                       in one pass over the particles each: the operations on every element and
  *                       their order are those of the separate calls, so are the results, bit for
  *                       bit (src/integrator.cpp:221-224 and :274 with the sum before it).
+ * nbpp_add_clear_kick_max_device   nbpp_add_clear_kick_device followed by nbpp_max_accel_sq_device
+ *                       on the new a (blocking, as that call is): the closing `acc += sum`, kick
+ *                       and max |a|^2 of a cycle (src/particles.cpp:362-364, src/integrator.cpp:274,
+ *                       :200-213) in one pass, the same value bit for bit.
  */
 int nbpp_kick_device(size_t n, double* vx, double* vy, double* vz,
                      const double* ax, const double* ay, const double* az,
@@ -276,6 +280,11 @@ int nbpp_add_clear_kick_device(size_t n, double* ax, double* ay, double* az,
                                double* bx, double* by, double* bz,
                                double* vx, double* vy, double* vz,
                                double dt, double scale_factor, double hubble, void* stream);
+int nbpp_add_clear_kick_max_device(size_t n, double* ax, double* ay, double* az,
+                                   double* bx, double* by, double* bz,
+                                   double* vx, double* vy, double* vz,
+                                   double dt, double scale_factor, double hubble,
+                                   double* out_host, void* stream);
 
 #ifdef __cplusplus
 }

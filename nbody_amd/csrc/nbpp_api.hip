@@ -1139,9 +1139,35 @@ int nbpp_add_clear_kick_device(size_t n, double* ax, double* ay, double* az, dou
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double a3 = scale_factor * scale_factor * scale_factor;
     const int blocks = std::min(2048, cdiv(static_cast<long long>(n), WG));
-    hipLaunchKernelGGL(k_add_clear_kick, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz, vx, vy, vz,
-                       dt / a3, dt * 2.0 * hubble);
+    hipLaunchKernelGGL(k_add_clear_kick<false>, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz, vx, vy, vz,
+                       dt / a3, dt * 2.0 * hubble, static_cast<double*>(nullptr));
     HIPCHK(hipGetLastError());
+    return NBPP_OK;
+}
+
+int nbpp_add_clear_kick_max_device(size_t n, double* ax, double* ay, double* az, double* bx, double* by,
+                                   double* bz, double* vx, double* vy, double* vz, double dt,
+                                   double scale_factor, double hubble, double* out_host, void* stream) {
+    if (!g.ready) return fail(NBPP_ERR_NOINIT, "nbpp_init has not been called");
+    if (!out_host) return fail(NBPP_ERR_ARG, "out_host is NULL");
+    *out_host = 1e-9;                                        // src/integrator.cpp:202
+    if (n == 0) return NBPP_OK;
+    if (!ax || !ay || !az || !bx || !by || !bz || !vx || !vy || !vz) return fail(NBPP_ERR_ARG, "NULL array pointer");
+    std::lock_guard<std::mutex> lock(g_mu);
+    HIPCHK(hipSetDevice(g.device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double a3 = scale_factor * scale_factor * scale_factor;
+    const int blocks = std::min(1024, cdiv(static_cast<long long>(n), WG));   // 1024 partial maxima fit g.pinned
+    CHK(g.blockmax.ensure(sizeof(double) * blocks));
+    hipLaunchKernelGGL(k_add_clear_kick<true>, dim3(blocks), dim3(WG), 0, s, n, ax, ay, az, bx, by, bz, vx, vy, vz,
+                       dt / a3, dt * 2.0 * hubble, g.blockmax.as<double>());
+    HIPCHK(hipGetLastError());
+    const double* h = static_cast<const double*>(g.pinned);
+    HIPCHK(hipMemcpyAsync(g.pinned, g.blockmax.p, sizeof(double) * blocks, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double m = 1e-9;
+    for (int b = 0; b < blocks; ++b) m = (h[b] > m) ? h[b] : m;  // strict '>' as src/integrator.cpp:209
+    *out_host = m;
     return NBPP_OK;
 }
 

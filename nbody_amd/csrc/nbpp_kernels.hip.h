@@ -1982,12 +1982,19 @@ __global__ void k_kick_drift(size_t n, double* __restrict__ x, double* __restric
     }
 }
 
-// k_add<true> then k_kick in one pass: a += b, b = 0, v kicked with the new a.
-__global__ void k_add_clear_kick(size_t n, double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
-                                 double* __restrict__ bx, double* __restrict__ by, double* __restrict__ bz,
-                                 double* __restrict__ vx, double* __restrict__ vy, double* __restrict__ vz,
-                                 double dt_over_a3, double dt_2H) {
+// k_add<true> then k_kick in one pass: a += b, b = 0, v kicked with the new a.  WITH_MAX: the
+// per-block maxima of k_max_accel_sq over the new a as well (the same roundings and the same
+// strict compares, so the reduced value is the separate kernel's bit for bit).
+template <bool WITH_MAX>
+__global__ void __launch_bounds__(WG) k_add_clear_kick(size_t n, double* __restrict__ ax, double* __restrict__ ay,
+                                                       double* __restrict__ az, double* __restrict__ bx,
+                                                       double* __restrict__ by, double* __restrict__ bz,
+                                                       double* __restrict__ vx, double* __restrict__ vy,
+                                                       double* __restrict__ vz, double dt_over_a3, double dt_2H,
+                                                       double* __restrict__ block_max) {
+    __shared__ double lds[WG / 64];
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    double m = 0.0;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double sx = __dadd_rn(ax[i], bx[i]), sy = __dadd_rn(ay[i], by[i]), sz = __dadd_rn(az[i], bz[i]);
         ax[i] = sx; ay[i] = sy; az[i] = sz;
@@ -1995,6 +2002,23 @@ __global__ void k_add_clear_kick(size_t n, double* __restrict__ ax, double* __re
         vx[i] = vx[i] + (__dmul_rn(sx, dt_over_a3) - __dmul_rn(vx[i], dt_2H));
         vy[i] = vy[i] + (__dmul_rn(sy, dt_over_a3) - __dmul_rn(vy[i], dt_2H));
         vz[i] = vz[i] + (__dmul_rn(sz, dt_over_a3) - __dmul_rn(vz[i], dt_2H));
+        if constexpr (WITH_MAX) {
+            const double s = __dadd_rn(__dadd_rn(__dmul_rn(sx, sx), __dmul_rn(sy, sy)), __dmul_rn(sz, sz));
+            m = (s > m) ? s : m;
+        }
+    }
+    if constexpr (WITH_MAX) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double o = __shfl_xor(m, d, 64);
+            m = (o > m) ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < WG / 64; ++w) m = (lds[w] > m) ? lds[w] : m;
+            block_max[blockIdx.x] = m;
+        }
     }
 }
 

@@ -24,6 +24,7 @@ EXPORTS = (
     "nbpp_accumulate_device_noalloc",
     "nbpp_accumulate_pairs_device", "nbpp_kick_device", "nbpp_drift_device", "nbpp_add_device",
     "nbpp_add_clear_device", "nbpp_kick_drift_device", "nbpp_add_clear_kick_device",
+    "nbpp_add_clear_kick_max_device",
     "nbpp_max_accel_sq_device",
 )
 
@@ -109,6 +110,8 @@ class Library:
         L.nbpp_add_clear_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_void_p]
         L.nbpp_kick_drift_device.argtypes = [C.c_size_t] + [_DP] * 9 + [C.c_double] * 5 + [C.c_void_p]
         L.nbpp_add_clear_kick_device.argtypes = [C.c_size_t] + [_DP] * 9 + [C.c_double] * 3 + [C.c_void_p]
+        L.nbpp_add_clear_kick_max_device.argtypes = [C.c_size_t] + [_DP] * 9 + [C.c_double] * 3 + \
+            [C.POINTER(C.c_double), C.c_void_p]
         L.nbpp_drift_device.argtypes = [C.c_size_t] + [_DP] * 6 + [C.c_double] * 2 + [C.c_void_p]
         L.nbpp_max_accel_sq_device.argtypes = [C.c_size_t] + [_DP] * 3 + [_DP, C.c_void_p]
         self._inited = False
@@ -202,6 +205,15 @@ class Library:
         """add_device(clear=True) then kick_device(dt) in one pass (nbpp_add_clear_kick_device)."""
         self._check(self.lib.nbpp_add_clear_kick_device(
             a[0].numel(), *[_dev(t) for t in (*a, *b, *v)], dt, scale_factor, hubble, C.c_void_p(stream or 0)))
+
+    def add_clear_kick_max_device(self, a, b, v, dt, scale_factor, hubble, stream=None):
+        """add_clear_kick_device then max_accel_sq_device(a) in one pass (nbpp_add_clear_kick_max_device);
+        blocking, returns the maximum."""
+        out = C.c_double(0.0)
+        self._check(self.lib.nbpp_add_clear_kick_max_device(
+            a[0].numel(), *[_dev(t) for t in (*a, *b, *v)], dt, scale_factor, hubble, C.byref(out),
+            C.c_void_p(stream or 0)))
+        return out.value
 
     def kick_device(self, v, a, dt, scale_factor, hubble, stream=None):
         self._check(self.lib.nbpp_kick_device(v[0].numel(), _dev(v[0]), _dev(v[1]), _dev(v[2]),

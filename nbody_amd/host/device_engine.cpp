@@ -218,7 +218,14 @@ void DeviceEngine::compute_accelerations() {
         hip_check(hipStreamWaitEvent(ms, static_cast<hipEvent_t>(ev_pp_), 0), "wait");
         // added and cleared in one pass: the next evaluation (which waits for this cycle's drift,
         // queued behind this kernel) finds zeros without a pass of its own in front of it
-        if (kick_after_forces_ > 0.0) {   // ... and the particles' closing half kick (:274) in the same pass
+        if (kick_after_forces_ > 0.0 && ranks_ == 0) {
+            // ... the particles' closing half kick (:274) and max |a|^2 (:261-262) in the same pass
+            nbpp_check(nbpp_add_clear_kick_max_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1],
+                                                      pp_acc_[2], dev_[3], dev_[4], dev_[5], kick_after_forces_,
+                                                      cosmo.scale_factor, cosmo.hubble_param, &max_accel_sq, main_));
+            kick_fused_ = true;
+            max_fused_ = true;
+        } else if (kick_after_forces_ > 0.0) {   // ... and the particles' closing half kick (:274) in the same pass
             nbpp_check(nbpp_add_clear_kick_device(n_, dev_[6], dev_[7], dev_[8], pp_acc_[0], pp_acc_[1], pp_acc_[2],
                                                   dev_[3], dev_[4], dev_[5], kick_after_forces_, cosmo.scale_factor,
                                                   cosmo.hubble_param, main_));
@@ -248,7 +255,9 @@ void DeviceEngine::compute_accelerations() {
     }
     pos_event_recorded_ = false;
     if (timed_) ++timed_force_calls;
-    if (!config_.STANDING_PARTICLES && ranks_ > 0) {                         // :261-262, over the ranks
+    if (max_fused_) {
+        max_fused_ = false;                                                  // read back with the sum and the kick
+    } else if (!config_.STANDING_PARTICLES && ranks_ > 0) {                  // :261-262, over the ranks
         nbmg_check(nbmg_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, main_));
     } else if (!config_.STANDING_PARTICLES) {
         nbpp_check(nbpp_max_accel_sq_device(n_, dev_[6], dev_[7], dev_[8], &max_accel_sq, main_));

@@ -103,6 +103,7 @@ class DeviceEngine {
     double gas_kick_after_mesh_ = 0.0;   // > 0: compute_accelerations() queues the gas's half kick of this length
     double kick_after_forces_ = 0.0;     // > 0: compute_accelerations() may kick the particles by this much with its sum
     bool kick_fused_ = false;            // ... and has done so
+    bool max_fused_ = false;             // ... together with max |a|^2 of the sum
     bool cfl_in_flight_ = false;         // the gas's CFL limit has been queued (nbgas_cfl_timestep_enqueue_device)
     bool pp_acc_zeroed_ = false;         // pp_acc_ holds zeros for the next overlapped evaluation
     bool pos_event_recorded_ = false;

@@ -469,6 +469,17 @@ def test_fused_kick_drift_and_add_clear_kick_equal_the_separate_calls(lib, oracl
         assert np.array_equal(ta[c].cpu().numpy(), s[c])
         assert not tb[c].cpu().numpy().any()
         assert np.array_equal(tv[c].cpu().numpy(), v[c])
+    # ... and with max |a|^2 of the sum read back in the same pass: the value of the separate call
+    b2 = [rng.standard_normal(n) * 1e-3 for _ in range(3)]
+    tb = _t(b2)
+    got_max = lib.add_clear_kick_max_device(ta, tb, tv, dt / 2, sc, H)
+    s2 = [s[c] + b2[c] for c in range(3)]
+    oracle.kick(v, s2, dt / 2, sc, H)
+    for c in range(3):
+        assert np.array_equal(ta[c].cpu().numpy(), s2[c])
+        assert not tb[c].cpu().numpy().any()
+        assert np.array_equal(tv[c].cpu().numpy(), v[c])
+    assert got_max == lib.max_accel_sq_device(ta) == oracle.max_accel_sq(s2)
 
 
 # --------------------------------------------------------------------------------------
