@@ -72,6 +72,13 @@ int nbgas_cfl_timestep_finish(const nbgas_params* p, double* dt_out);
 int nbgas_kick_device(const nbgas_params* p, const nbgas_state* s, const double* gx,
                       const double* gy, const double* gz, double dt, double scale_factor,
                       double hubble, void* stream);
+/* nbgas_kick_device followed by nbgas_cfl_timestep_enqueue_device in one pass over the meshes: the
+ * reduction of get_cfl_timestep (src/gas.cpp:301-323) reads the pressure and velocities the kick
+ * has just stored (src/integrator.cpp:139), so the kick hands them to it directly.  The time step
+ * is collected with nbgas_cfl_timestep_finish, the same value as after the two separate calls. */
+int nbgas_kick_cfl_enqueue_device(const nbgas_params* p, const nbgas_state* s, const double* gx,
+                                  const double* gy, const double* gz, double dt,
+                                  double scale_factor, double hubble, void* stream);
 
 /* total = dm_density + gas density: the source of the mesh solve (src/integrator.cpp:57-59). */
 int nbgas_total_density_device(const nbgas_params* p, const nbgas_state* s,

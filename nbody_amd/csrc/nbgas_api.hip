@@ -26,6 +26,7 @@ static_assert(NBGAS_OK == nbc::OK && NBGAS_ERR_ARG == nbc::ERR_ARG && NBGAS_ERR_
 
 constexpr int WG = 256;
 constexpr double FLOOR = 1e-12;
+constexpr unsigned PINNED_DOUBLES = 16384;   // partial maxima the CFL read-back can carry (128 KiB)
 
 using nbc::Buf;
 using nbc::cdiv;
@@ -36,7 +37,7 @@ struct Ctx {
     int device = -1;
     Buf scratch;     // five conserved meshes: the other side of the sweeps' ping-pong
     Buf blockmax;
-    void* pinned = nullptr;   // 8 KiB of page-locked host memory for the CFL read-back
+    void* pinned = nullptr;   // PINNED_DOUBLES of page-locked host memory for the CFL read-back
     hipEvent_t cfl_done = nullptr;   // the read-back of nbgas_cfl_timestep_enqueue_device has landed
     unsigned cfl_blocks = 0;         // partial maxima in flight (0: nothing enqueued)
 };
@@ -183,29 +184,73 @@ __global__ void __launch_bounds__(WG) k_signal_max(size_t total, double gamma, n
     }
 }
 
-// apply_gas_kick (src/integrator.cpp:139-165), primitives included
+// out[block] = max of the block's grid-stride share of in[0 .. n)
+__global__ void __launch_bounds__(WG) k_max_of(unsigned n, const double* __restrict__ in, double* __restrict__ out) {
+    __shared__ double lds[WG / 64];
+    double m = -INFINITY;
+    for (unsigned i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) m = (in[i] > m) ? in[i] : m;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double o = __shfl_xor(m, d, 64);
+        m = (o > m) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < WG / 64; ++w) m = (lds[w] > m) ? lds[w] : m;
+        out[blockIdx.x] = m;
+    }
+}
+
+// apply_gas_kick (src/integrator.cpp:139-165), primitives included.  WITH_SIGNAL: the per-block
+// maxima of k_signal_max as well, from the very pressure and velocities this kernel stores (the
+// ones a CFL reduction right after it would read back): one block per WG cells, block_max sized
+// to the grid.
+template <bool WITH_SIGNAL>
 __global__ void __launch_bounds__(WG) k_gas_kick(size_t total, double gamma, nbgas_state s,
                                                  const double* __restrict__ gx, const double* __restrict__ gy,
                                                  const double* __restrict__ gz, double dt, double a3,
-                                                 double two_H) {
+                                                 double two_H, double* __restrict__ block_max) {
+    __shared__ double lds[WG / 64];
     const size_t idx = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
-    if (idx >= total) return;
-    const double gm1 = gamma - 1.0, inv_gm1 = 1.0 / gm1;
-    Conserved u;
-    u.rho = s.density[idx]; u.m[0] = s.momentum_x[idx]; u.m[1] = s.momentum_y[idx];
-    u.m[2] = s.momentum_z[idx]; u.en = s.energy[idx];
-    const Cell c = primitives(u, gm1, inv_gm1);
-    const double tx = (gx[idx] / a3) - (two_H * c.v[0]);
-    const double ty = (gy[idx] / a3) - (two_H * c.v[1]);
-    const double tz = (gz[idx] / a3) - (two_H * c.v[2]);
-    const double sx = c.rho * tx, sy = c.rho * ty, sz = c.rho * tz;
-    const double power = c.v[0] * sx + c.v[1] * sy + c.v[2] * sz;
-    s.momentum_x[idx] = c.m[0] + sx * dt;
-    s.momentum_y[idx] = c.m[1] + sy * dt;
-    s.momentum_z[idx] = c.m[2] + sz * dt;
-    s.energy[idx] = c.en + power * dt;
-    s.pressure[idx] = c.p;
-    s.velocity_x[idx] = c.v[0]; s.velocity_y[idx] = c.v[1]; s.velocity_z[idx] = c.v[2];
+    double signal = -INFINITY;
+    if (idx < total) {
+        const double gm1 = gamma - 1.0, inv_gm1 = 1.0 / gm1;
+        Conserved u;
+        u.rho = s.density[idx]; u.m[0] = s.momentum_x[idx]; u.m[1] = s.momentum_y[idx];
+        u.m[2] = s.momentum_z[idx]; u.en = s.energy[idx];
+        const Cell c = primitives(u, gm1, inv_gm1);
+        const double tx = (gx[idx] / a3) - (two_H * c.v[0]);
+        const double ty = (gy[idx] / a3) - (two_H * c.v[1]);
+        const double tz = (gz[idx] / a3) - (two_H * c.v[2]);
+        const double sx = c.rho * tx, sy = c.rho * ty, sz = c.rho * tz;
+        const double power = c.v[0] * sx + c.v[1] * sy + c.v[2] * sz;
+        s.momentum_x[idx] = c.m[0] + sx * dt;
+        s.momentum_y[idx] = c.m[1] + sy * dt;
+        s.momentum_z[idx] = c.m[2] + sz * dt;
+        s.energy[idx] = c.en + power * dt;
+        s.pressure[idx] = c.p;
+        s.velocity_x[idx] = c.v[0]; s.velocity_y[idx] = c.v[1]; s.velocity_z[idx] = c.v[2];
+        if constexpr (WITH_SIGNAL) {                      // src/gas.cpp:304-318 on the stored values
+            double cs_sq = gamma * c.p / c.rho;
+            cs_sq = (c.rho > FLOOR) ? cs_sq : 0.0;
+            cs_sq = (cs_sq == cs_sq) ? cs_sq : 0.0;
+            signal = sqrt(c.v[0] * c.v[0] + c.v[1] * c.v[1] + c.v[2] * c.v[2]) + sqrt(cs_sq);
+            signal = (signal == signal) ? signal : -INFINITY;   // a NaN signal is skipped, as by Eigen's maxCoeff
+        }
+    }
+    if constexpr (WITH_SIGNAL) {
+        double m = signal;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double o = __shfl_xor(m, d, 64);
+            m = (o > m) ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < WG / 64; ++w) m = (lds[w] > m) ? lds[w] : m;
+            block_max[blockIdx.x] = m;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(WG) k_total_density(size_t total, const double* __restrict__ dm,
@@ -281,7 +326,7 @@ int nbgas_init(int device) {
     }
     if (device < 0 || device >= count) return fail(NBGAS_ERR_ARG, "device %d out of range [0, %d)", device, count);
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipHostMalloc(&g.pinned, 8192, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&g.pinned, sizeof(double) * PINNED_DOUBLES, hipHostMallocDefault));
     g.device = device;
     g.ready = true;
     return NBGAS_OK;
@@ -378,9 +423,36 @@ int nbgas_kick_device(const nbgas_params* p, const nbgas_state* s, const double*
     if (!gx || !gy || !gz) return fail(NBGAS_ERR_ARG, "NULL mesh acceleration");
     const size_t total = static_cast<size_t>(p->mesh_size) * p->mesh_size * p->mesh_size;
     const double a3 = scale_factor * scale_factor * scale_factor;          // src/integrator.cpp:140
-    hipLaunchKernelGGL(k_gas_kick, dim3(cdiv(total, WG)), dim3(WG), 0, static_cast<hipStream_t>(stream), total,
-                       p->gamma, *s, gx, gy, gz, dt, a3, 2 * hubble);
+    hipLaunchKernelGGL(k_gas_kick<false>, dim3(cdiv(total, WG)), dim3(WG), 0, static_cast<hipStream_t>(stream), total,
+                       p->gamma, *s, gx, gy, gz, dt, a3, 2 * hubble, static_cast<double*>(nullptr));
     HIPCHK(hipGetLastError());
+    return NBGAS_OK;
+}
+
+int nbgas_kick_cfl_enqueue_device(const nbgas_params* p, const nbgas_state* s, const double* gx, const double* gy,
+                                  const double* gz, double dt, double scale_factor, double hubble, void* stream) {
+    ENTER();
+    CHK(check(p, s));
+    if (!gx || !gy || !gz) return fail(NBGAS_ERR_ARG, "NULL mesh acceleration");
+    const size_t total = static_cast<size_t>(p->mesh_size) * p->mesh_size * p->mesh_size;
+    const unsigned blocks = cdiv(total, WG);
+    CHK(g.blockmax.ensure(sizeof(double) * (blocks + PINNED_DOUBLES)));
+    if (!g.cfl_done) HIPCHK(hipEventCreateWithFlags(&g.cfl_done, hipEventDisableTiming));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double a3 = scale_factor * scale_factor * scale_factor;          // src/integrator.cpp:140
+    double* partial = g.blockmax.as<double>();
+    hipLaunchKernelGGL(k_gas_kick<true>, dim3(blocks), dim3(WG), 0, st, total, p->gamma, *s, gx, gy, gz, dt, a3,
+                       2 * hubble, partial);
+    unsigned left = blocks;
+    if (left > PINNED_DOUBLES) {   // more partial maxima than the page-locked buffer holds: one more, small pass
+        hipLaunchKernelGGL(k_max_of, dim3(PINNED_DOUBLES / 4), dim3(WG), 0, st, left, partial, partial + blocks);
+        partial += blocks;
+        left = PINNED_DOUBLES / 4;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g.pinned, partial, sizeof(double) * left, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(g.cfl_done, st));
+    g.cfl_blocks = left;
     return NBGAS_OK;
 }
 

@@ -378,7 +378,7 @@ GAS_LIB_PATH = os.environ.get("NBGAS_LIB") or os.path.join(HERE, "lib", "libnbga
 GAS_EXPORTS = (
     "nbgas_init", "nbgas_shutdown", "nbgas_last_error", "nbgas_update_primitives_device",
     "nbgas_hydro_step_device", "nbgas_cfl_timestep_device", "nbgas_cfl_timestep_enqueue_device",
-    "nbgas_cfl_timestep_finish", "nbgas_kick_device",
+    "nbgas_cfl_timestep_finish", "nbgas_kick_device", "nbgas_kick_cfl_enqueue_device",
     "nbgas_total_density_device", "nbgas_initialize_device",
 )
 
@@ -421,6 +421,7 @@ class GasLibrary:
         L.nbgas_cfl_timestep_enqueue_device.argtypes = [P, S, C.c_void_p]
         L.nbgas_cfl_timestep_finish.argtypes = [P, C.POINTER(C.c_double)]
         L.nbgas_kick_device.argtypes = [P, S] + [_DP] * 3 + [C.c_double] * 3 + [C.c_void_p]
+        L.nbgas_kick_cfl_enqueue_device.argtypes = [P, S] + [_DP] * 3 + [C.c_double] * 3 + [C.c_void_p]
         L.nbgas_total_density_device.argtypes = [P, S, _DP, _DP, C.c_void_p]
         L.nbgas_initialize_device.argtypes = [P, S] + [_DP] * 4 + [C.c_double] * 3 + [C.c_int, C.c_double,
                                                                                      C.c_void_p]
@@ -477,6 +478,13 @@ class GasLibrary:
         self._check(self.lib.nbgas_kick_device(C.byref(p), C.byref(s), _dev(grav[0]), _dev(grav[1]),
                                                _dev(grav[2]), dt, scale_factor, hubble,
                                                C.c_void_p(stream or 0)))
+
+    def kick_cfl_enqueue_device(self, p, tensors, grav, dt, scale_factor, hubble, stream=None):
+        """kick_device then cfl_timestep_enqueue_device in one pass (nbgas_kick_cfl_enqueue_device)."""
+        s = self.state(tensors)
+        self._check(self.lib.nbgas_kick_cfl_enqueue_device(C.byref(p), C.byref(s), _dev(grav[0]), _dev(grav[1]),
+                                                           _dev(grav[2]), dt, scale_factor, hubble,
+                                                           C.c_void_p(stream or 0)))
 
     def total_density_device(self, p, tensors, dm_density, total, stream=None):
         s = self.state(tensors)

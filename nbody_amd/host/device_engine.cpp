@@ -195,15 +195,18 @@ void DeviceEngine::compute_accelerations() {
         if (config_.USE_HYDRO && gas_kick_after_mesh_ > 0.0) {
             const nbgas_params gp = config_.gas_params();
             const nbgas_state gs = gas_state();
-            nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], gas_kick_after_mesh_,
-                                          cosmo.scale_factor, cosmo.hubble_param, main_));
-            gas_kick_after_mesh_ = 0.0;
             // ... and nothing touches the gas until the next cycle: the CFL limit of the next step
-            // (src/engine.cpp:18) is reduced and read back now, collected in cfl_timestep()
+            // (src/engine.cpp:18) is reduced in the same pass and read back now, collected in
+            // cfl_timestep()
             if (config_.USE_ADAPTIVE_DT) {
-                nbgas_check(nbgas_cfl_timestep_enqueue_device(&gp, &gs, main_));
+                nbgas_check(nbgas_kick_cfl_enqueue_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], gas_kick_after_mesh_,
+                                                          cosmo.scale_factor, cosmo.hubble_param, main_));
                 cfl_in_flight_ = true;
+            } else {
+                nbgas_check(nbgas_kick_device(&gp, &gs, mesh_[2], mesh_[3], mesh_[4], gas_kick_after_mesh_,
+                                              cosmo.scale_factor, cosmo.hubble_param, main_));
             }
+            gas_kick_after_mesh_ = 0.0;
         }
     }
     if (!config_.USE_PM) {                                                   // :246-251
