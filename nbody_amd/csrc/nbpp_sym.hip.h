@@ -59,6 +59,10 @@ __device__ __forceinline__ double rotate_lane(double v) {
 // (Moving the coordinates through the LDS crossbar instead, ds_bpermute_b32 issued at the start
 // of a step, was measured slower: the extra live registers spill at 4 waves/SIMD and 3 waves/SIMD
 // loses more than the six DPP moves cost.)
+// (Nor does keeping the visited tile in LDS help - every lane reading entry (lane + step) mod 64 and
+// adding its reaction there with ds_add_f64, no rotation at all, ten VALU instructions fewer per
+// step of 104: 1.67 s against 1.63 s per 128^3 evaluation, 1.74 s with the next record requested a
+// step ahead, which spills.)
 
 // One evaluation, both directions.  (dx,dy,dz) points from i to j.
 template <bool SOFT0, bool WEIGHTED>
