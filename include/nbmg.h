@@ -117,7 +117,8 @@ int nbmg_allreduce_max_device(size_t count, double* data, void* stream);
  * accelerations, accumulated into.  The call all-gathers the positions into arrays the library
  * owns, then
  *   - P3M (use_pm), or direct summation without pair shares: nbpp_accumulate_device with the
- *     rank's block as the target range; no reduction; bitwise reproducible;
+ *     rank's block as the target range; no reduction; bitwise reproducible with
+ *     NBPP_OPT_DETERMINISTIC;
  *   - direct summation with pair shares (default on more than one rank):
  *     nbpp_accumulate_pairs_device evaluates share `rank` of the unordered pairs into zeroed
  *     full-length sums, ncclReduceScatter leaves each rank the complete sums of its block, which

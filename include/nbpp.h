@@ -82,7 +82,9 @@ typedef struct nbpp_stats {
     int32_t  p3m_pooled;     /* NBPP_KERNEL_P3M_CELLS: 0 if each lane evaluated its own
                                 survivors of the cutoff pre-filter, 1 if they were pooled per
                                 wavefront (NBPP_OPT_P3M_POOLED_DRAIN), 2 if every unordered
-                                pair was evaluated once (NBPP_OPT_P3M_PAIR_ONCE)             */
+                                pair was evaluated once (NBPP_OPT_P3M_PAIR_ONCE), 3 if the
+                                lanes of a target walked its rows together
+                                (NBPP_OPT_P3M_ROW_LANES)                                     */
     double   cell_occupancy; /* NBPP_KERNEL_P3M_CELLS: mean over particles of the number of
                                 particles in the particle's own search cell (1 + the mean
                                 per cell when evenly spread; grows with clustering)          */
@@ -110,8 +112,12 @@ enum {
                                     0 = automatic                                        */
     NBPP_OPT_NO_EQUAL_MASS_PATH = 6, /* 1 = always multiply by the source mass per pair, even
                                     when all masses are equal (testing)                  */
-    NBPP_OPT_DETERMINISTIC = 7,  /* 1 = never pick NBPP_KERNEL_DIRECT_SYMMETRIC by itself:
-                                    results are then bitwise reproducible from run to run */
+    NBPP_OPT_DETERMINISTIC = 7,  /* 1 = results bitwise reproducible from run to run: never
+                                    NBPP_KERNEL_DIRECT_SYMMETRIC nor the pooled or pair-once P3M
+                                    kernels by themselves, and the members of every search cell
+                                    put into a fixed order before the P3M pair kernel (by default
+                                    their order, and so the last bits of the sums, is whatever
+                                    the binning's atomics left)                              */
     NBPP_OPT_P3M_LANES_PER_TARGET = 8, /* P3M cell kernel: 0 = automatic (more lanes the fewer
                                     targets), else 1, 2, 4, 8 or 16                       */
     NBPP_OPT_P3M_POOLED_DRAIN = 9, /* P3M cell kernel with one lane per target: 0 = automatic (pool
@@ -127,6 +133,12 @@ enum {
                                     LDS and NBPP_OPT_DETERMINISTIC is off; not tried in the call
                                     after one that found the particles clustered,
                                     cell_occupancy >= 6.5), 1 = whenever it fits, -1 = never   */
+    NBPP_OPT_P3M_ROW_LANES = 12, /* P3M cell kernel on small sets: lanes of one target that walk every
+                                    row of its neighbourhood together, each taking every G-th
+                                    candidate (balanced whatever the rows hold; wasteful where rows
+                                    are short): 0 = automatic (8 lanes, for every call that would
+                                    otherwise get several lanes per target, i.e. small sets),
+                                    -1 = never, else 4, 8, 16, 32 or 64                          */
     NBPP_OPT_P3M_POOL_WORKGROUP = 11 /* threads per workgroup of the pooled P3M kernel: 0 = 64, else
                                     64, 128 or 256.  Its wavefronts work independently, and alone
                                     on the GPU the kernel is 4-8 % faster with one wavefront per

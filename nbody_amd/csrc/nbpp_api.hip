@@ -145,7 +145,7 @@ struct Ctx : Work {
     int sym_skip_left = 0;
     int sym_skip_n = 0, sym_skip_nside = 0;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0, opt_pool_wg = 0;
+            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0, opt_pool_wg = 0, opt_row_lanes = 0;
     nbpp_stats stats{};
 };
 
@@ -605,7 +605,14 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // k_p3m_cells on jittered lattices, pair kernel alone, 0.125 / 0.131 ms at 64^3,
     // 0.673 / 0.711 at 128^3, 2.05 / 2.30 at 192^3, 4.67 / 5.00 at 256^3.
     const bool table_fits = static_cast<unsigned long long>(ncell) <= START_TABLE_CHECKED_MAX_CELLS;
-    const bool sym = all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
+    // G lanes of a target walking every row together (k_p3m_rows) instead of several lanes of a
+    // target owning whole rows each: every call that would get more than one lane per target
+    int row_lanes = 0;
+    if (!wide && table_fits) {
+        if (g.opt_row_lanes > 0) row_lanes = static_cast<int>(g.opt_row_lanes);
+        else if (g.opt_row_lanes == 0 && g.opt_p3m_lanes == 0 && lanes > 1) row_lanes = P3M_ROWS_LANES;
+    }
+    const bool sym = row_lanes == 0 && all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
                      n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
                      (g.opt_p3m_sym > 0 ||
                       (g.opt_p3m_sym == 0 && !g.opt_deterministic && lanes == 1 && occupancy < 6.0));
@@ -615,7 +622,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // measure 2.6) 4.79 against 5.08 ms; the 128^3 run at a = 0.25 (2.9) 0.93 against 1.00 ms, at
     // a = 0.33 (3.4) 1.07 against 1.22, at a = 0.40 (4.4) 1.23 against 1.47, at a = 0.51 (7.3) 1.40
     // against 1.96; 400 tight blobs 12.5 against 14.8 ms.
-    const bool pooled = lanes == 1 && (g.opt_p3m_pooled > 0 || (g.opt_p3m_pooled == 0 && !g.opt_deterministic));
+    const bool pooled = row_lanes == 0 && lanes == 1 &&
+                        (g.opt_p3m_pooled > 0 || (g.opt_p3m_pooled == 0 && !g.opt_deterministic));
 
     // 2. scatter and records.  k_p3m_cells promises sums that repeat from run to run: the members
     // of every cell are put into ascending original order before their records are gathered.  The
@@ -624,7 +632,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // 0.38 ms of binning on the clustered 128^3 set, 0.1 of 0.9 ms on the 256^3 lattice).  (Writing
     // the records from the scatter itself, without a gather, was measured too: the scattered
     // 4-byte stores cost more than the gather's reads, 0.87 against 0.81 ms at 256^3.)
-    const bool fixed_order = !(sym || pooled);
+    const bool fixed_order = !(sym || pooled || (row_lanes > 0 && !g.opt_deterministic));
     CHK(g.src.order.ensure(sizeof(int) * n_entries));
     CHK(g.src.x.ensure(sizeof(double4) * n_entries));  // AoS records live in the x buffer
     int* entries = g.src.order.as<int>();
@@ -688,6 +696,24 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         else hipLaunchKernelGGL((k_p3m_sym<false>), bricks, dim3(SYM_WG), 0, s, a, nbx, nby, nbz);
         HIPCHK(hipGetLastError());
         g.stats.p3m_pooled = 2;
+        g.stats.pairs_evaluated = 0;
+        g.stats.pair_launches = 1;
+        return NBPP_OK;
+    }
+    if (row_lanes > 0) {
+        const dim3 rows_grid(cdiv(static_cast<long long>(n_tgt) * row_lanes, 64)), rows_wg(64);
+#define NBPP_LAUNCH_ROWS(S0)                                                                         \
+    switch (row_lanes) {                                                                             \
+        case 4: hipLaunchKernelGGL((k_p3m_rows<S0, 4>), rows_grid, rows_wg, 0, s, a); break;         \
+        case 8: hipLaunchKernelGGL((k_p3m_rows<S0, 8>), rows_grid, rows_wg, 0, s, a); break;         \
+        case 16: hipLaunchKernelGGL((k_p3m_rows<S0, 16>), rows_grid, rows_wg, 0, s, a); break;       \
+        case 32: hipLaunchKernelGGL((k_p3m_rows<S0, 32>), rows_grid, rows_wg, 0, s, a); break;       \
+        default: hipLaunchKernelGGL((k_p3m_rows<S0, 64>), rows_grid, rows_wg, 0, s, a); break;       \
+    }
+        if (soft0) { NBPP_LAUNCH_ROWS(true) } else { NBPP_LAUNCH_ROWS(false) }
+#undef NBPP_LAUNCH_ROWS
+        HIPCHK(hipGetLastError());
+        g.stats.p3m_pooled = 3;
         g.stats.pairs_evaluated = 0;
         g.stats.pair_launches = 1;
         return NBPP_OK;
@@ -876,6 +902,11 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_P3M_LANES_PER_TARGET: g.opt_p3m_lanes = value; return NBPP_OK;
         case NBPP_OPT_P3M_POOLED_DRAIN: g.opt_p3m_pooled = value; return NBPP_OK;
         case NBPP_OPT_P3M_PAIR_ONCE: g.opt_p3m_sym = value; return NBPP_OK;
+        case NBPP_OPT_P3M_ROW_LANES:
+            if (value != 0 && value != -1 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
+                return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_ROW_LANES takes 0, -1, 8, 16, 32 or 64");
+            g.opt_row_lanes = value;
+            return NBPP_OK;
         case NBPP_OPT_P3M_POOL_WORKGROUP:
             if (value != 0 && value != 64 && value != 128 && value != 256)
                 return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_POOL_WORKGROUP takes 0, 64, 128 or 256");

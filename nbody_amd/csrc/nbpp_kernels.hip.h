@@ -1547,6 +1547,128 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// The same search with G lanes of a wavefront walking every row of ONE target together.
+//
+// Small particle sets cannot fill the GPU with a lane per target, and once they have clustered
+// their work sits in a few thousand targets whose heaviest rows hold thousands of candidates:
+// k_p3m_cells gives a target up to 16 lanes, but a lane owns whole rows, and the wavefront waits for
+// the lane that got the row through the dense cell (32^3 at a = 0.9: 5.6 M accepted pairs in 0.2 ms,
+// 28 G/s, where the arithmetic is 11 us of the GPU).  Here lane `sub` of a target's G lanes takes
+// candidates sub, sub + G, ... of every row - consecutive lanes read consecutive 32-byte records - so
+// the lanes of a target finish together whatever the rows hold.  No fp32 pre-filter: with one target
+// per group the row is trimmed to the cells its cutoff sphere meets (row_window), after which more
+// than half of the candidates are accepted, and the exact test on the fp64 record costs less than
+// the filter's queue.  Every lane sums its own candidates in order and the G partial sums are added
+// in a fixed tree, so with the members of a cell in a fixed order the result is reproducible.
+// It takes the calls that k_p3m_cells would have taken with several lanes per target (small
+// sets): measured against that kernel at its own best lane count, pair kernel alone, with 8 lanes
+// per target (4 and 16 are within 10 % of it, 32 and 64 waste most lanes on short rows): the
+// reference's shipped 32^3 run at a = 0.29 / 0.45 / 0.65 / 0.90 0.058 / 0.068 / 0.080 / 0.089 ms
+// against 0.050 / 0.083 / 0.127 / 0.189 ms, a 64^3 run at a = 0.45 / 0.62 / 0.83 0.28 / 0.34 /
+// 0.45 ms against 0.34 / 0.61 / 0.97 ms; and since it needs no particular order inside a cell
+// unless reproducible sums are asked for, the binning before it is five launches shorter (0.056
+// against 0.07-0.09 ms at 32^3), which pays for the one state where the kernel itself is slower.
+// ---------------------------------------------------------------------------------
+constexpr int P3M_ROWS_ABREAST = 2;   // rows of a target walked side by side (1, 2, 4: 0.061 / 0.058 / 0.058 ms on a
+                                      // near-uniform 32^3 set, 0.089 / 0.091 / 0.099 ms on a clustered one)
+constexpr int P3M_ROWS_LANES = 8;     // lanes per target when the kernel is chosen by itself
+
+template <bool SOFT0, int G>
+__global__ void __launch_bounds__(64) k_p3m_rows(const P3MArgs a) {
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "lanes per target");
+    constexpr int PER_WAVE = 64 / G;
+    const int lane = threadIdx.x, sub = lane % G;
+    const int t = static_cast<int>(blockIdx.x) * PER_WAVE + lane / G;
+    const bool live = t < a.n_tgt;
+    const int p = a.tlist[live ? t : a.n_tgt - 1];
+    const double4 me = a.rec[p];
+    const GhostGrid g = a.g;
+    const PairConsts k = a.k;
+    const int pcx = bin_coord(me.x, g.scale, g.nside) + g.R;
+    const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
+    const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
+    const RowTrim trim = make_row_trim(me, pcx, pcy, pcz, g, k);
+    const StartTable<true> starts = make_start_table<true>(a.cell_start, g);
+    const uint32_t rec_bytes = static_cast<uint32_t>(a.n_entries) << 5;
+    const __amdgpu_buffer_rsrc_t rec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    unsigned hits = 0;
+    const int span = 2 * g.R + 1;
+    const int n_rows = span * span;
+    // bounds of the part of row `row` this target can reach (none for a padding lane or past the last row)
+    auto row_bounds = [&](int row, int& j, int& je) {
+        const int ox = row / span, oy = row - ox * span;
+        int zlo = 0, zhi = 0;
+        const bool reach = row_window(trim, ox - g.R, oy - g.R, g.R, zlo, zhi);
+        const bool has = live && row < n_rows && reach;
+        const int base = ((pcx - g.R + ox) * g.np + (pcy - g.R + oy)) * g.np + pcz;
+        j = load_start(starts, base + zlo, has);
+        je = load_start(starts, base + zhi + 1, has);
+    };
+    auto candidate = [&](const double4& s, bool valid, int j) {
+        const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+        const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+        if (valid && j != p && !(r2 > k.cutoff_sq)) {      // the reference's cutoff test (src/particles.cpp:326)
+            p3m_accepted<SOFT0>(dx, dy, dz, r2, s.w, k, ax, ay, az);
+            ++hits;
+        }
+    };
+    // ROWS rows are walked side by side, two candidates of each per trip: most rows of a small set
+    // are a handful of candidates long, and one row at a time the kernel does little but wait for
+    // the next row's bounds and records
+    constexpr int ROWS = P3M_ROWS_ABREAST;
+    int nj[ROWS], nje[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) row_bounds(r, nj[r], nje[r]);
+#pragma unroll 1
+    for (int row = 0; row < n_rows; row += ROWS) {
+        int j[ROWS], je[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { j[r] = nj[r] + sub; je[r] = nje[r]; }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) row_bounds(row + ROWS + r, nj[r], nje[r]);   // in flight while these rows are walked
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) any |= j[r] < je[r];
+            if (!__any(any)) break;
+            double4 s[ROWS][2];
+            bool v[ROWS][2];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    v[r][u] = j[r] + u * G < je[r];
+                    s[r][u] = load_record_checked(rec_rsrc, v[r][u] ? static_cast<uint32_t>(j[r] + u * G) << 5 : 0xffffffe0u);
+                }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) candidate(s[r][u], v[r][u], j[r] + u * G);
+                j[r] += 2 * G;
+            }
+        }
+    }
+    // the G lanes of a target sit next to each other: fixed-order tree sum
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        ax += __shfl_xor(ax, d, 64);
+        ay += __shfl_xor(ay, d, 64);
+        az += __shfl_xor(az, d, 64);
+    }
+    if (live && sub == 0) {
+        const int o = a.entries[p] - a.tgt_begin;
+        a.ax[o] += ax; a.ay[o] += ay; a.az[o] += az;
+    }
+    if (a.accepted) {
+        unsigned long long h = live ? hits : 0u;
+        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        if (lane == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Every unordered pair once (Newton's third law) for the P3M short range.
 //
 // The reference evaluates (i, j) and (j, i) separately (src/particles.cpp:270-365); their

@@ -856,22 +856,26 @@ def test_host_mapped_outputs_never_get_the_atomic_kernel(lib, oracle):
 def test_page_locked_caller_arrays_give_the_same_sums(lib, use_pm):
     """nbpp_accumulate from page-locked arrays (nbpp_host_alloc: DMA in, sums added in place by
     the device) against the same call on pageable arrays (staged, added by host threads): the
-    same kernels and one rounding per accumulator either way, so bit for bit."""
+    same kernels and one rounding per accumulator either way, so bit for bit (with reproducible
+    sums asked for: by default the order of a cell's members, and with it the last bits of the
+    short-range sums, is whatever the binning's atomics left)."""
     n_side = 20
     n = n_side ** 3
     pos = datasets.jittered_lattice(n_side, seed=4)
     m = datasets.masses(n, equal=False)
     p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm).pp_params()
     start = [np.full(n, 0.25), np.full(n, -1.0), np.zeros(n)]
-    plain = gpu_acc(lib, p, pos, m, acc0=start)
+    lib.set_option(ffi.OPT_DETERMINISTIC, 1)
     arrays = [lib.host_alloc(n) for _ in range(7)]
     try:
+        plain = gpu_acc(lib, p, pos, m, acc0=start)
         for dst, src in zip(arrays, (*pos, m, *start)):
             dst[:] = src
         lib.accumulate(p, *arrays)
         for got, want in zip(arrays[4:], plain):
             assert np.array_equal(got, want)
     finally:
+        lib.set_option(ffi.OPT_DETERMINISTIC, 0)
         for a in arrays:
             lib.host_free(a)
 
@@ -926,6 +930,68 @@ def test_p3m_pooled_drain_equals_per_lane_drain(lib, oracle, name, n_side):
     n_tgt = 4096
     want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=O.EXACT_CELLS)
     assert normalised_error([a[:n_tgt] for a in out[1]], want, floor) < TOL
+
+
+@pytest.mark.parametrize("row_lanes", [4, 8, 16, 32, 64])
+@pytest.mark.parametrize("name", ["clustered", "lattice_soft0"])
+def test_p3m_lanes_walking_rows_together(lib, oracle, name, row_lanes):
+    """k_p3m_rows (NBPP_OPT_P3M_ROW_LANES): 4 to 64 lanes of a target take every G-th candidate of
+    each of its rows.  Exact accepted-pair count against the oracle, sums within the parity bar
+    (ragged target count, unequal masses, blobs whose cells hold hundreds of particles; zero
+    softening on a lattice), and - with the members of a cell in a fixed order
+    (NBPP_OPT_DETERMINISTIC) - the same bits from one call to the next."""
+    n_side = 28
+    n = n_side ** 3 - 11
+    if name == "clustered":
+        pos = datasets.clustered(n, n_blobs=9, sigma=0.02, seed=5)
+        m = datasets.masses(n, equal=False)
+    else:
+        pos = [c[:n].copy() for c in datasets.jittered_lattice(n_side, jitter=0.9)]
+        m = datasets.masses(n, equal=True)
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    if name == "lattice_soft0":
+        config.SOFTENING_SQUARED = 0.0
+    p = config.pp_params()
+    try:
+        lib.set_option(ffi.OPT_P3M_ROW_LANES, row_lanes)
+        lib.set_option(ffi.OPT_DETERMINISTIC, 1)
+        got = gpu_acc(lib, p, pos, m)
+        st = lib.stats()
+        again = gpu_acc(lib, p, pos, m)
+        with pytest.raises(ffi.NbppError):
+            lib.set_option(ffi.OPT_P3M_ROW_LANES, 12)
+    finally:
+        lib.set_option(ffi.OPT_P3M_ROW_LANES, 0)
+        lib.set_option(ffi.OPT_DETERMINISTIC, 0)
+    assert st["kernel_variant"] == ffi.KERNEL_P3M_CELLS and st["p3m_pooled"] == 3
+    assert st["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
+    for c in range(3):
+        assert np.array_equal(got[c], again[c])
+    n_tgt = 3000
+    want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=O.EXACT_CELLS)
+    assert normalised_error([a[:n_tgt] for a in got], want, pair_force_scale(p, m, n) * 1e-3) < TOL
+
+
+def test_small_sets_get_the_row_walking_kernel_by_themselves(lib, oracle):
+    """A set small enough to get several lanes per target is given k_p3m_rows; a forced lane count
+    (NBPP_OPT_P3M_LANES_PER_TARGET) or NBPP_OPT_P3M_ROW_LANES = -1 keeps k_p3m_cells."""
+    n_side = 24
+    pos = datasets.jittered_lattice(n_side)
+    m = datasets.masses(n_side ** 3, equal=True)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True).pp_params()
+    kinds = {}
+    try:
+        for label, key, value in (("auto", ffi.OPT_P3M_ROW_LANES, 0), ("never", ffi.OPT_P3M_ROW_LANES, -1),
+                                  ("lanes", ffi.OPT_P3M_LANES_PER_TARGET, 4)):
+            lib.set_option(key, value)
+            kinds[label] = (gpu_acc(lib, p, pos, m), lib.stats()["p3m_pooled"])
+            lib.set_option(key, 0)
+    finally:
+        lib.set_option(ffi.OPT_P3M_ROW_LANES, 0)
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
+    assert kinds["auto"][1] == 3 and kinds["never"][1] == 0 and kinds["lanes"][1] == 0
+    floor = pair_force_scale(p, m, n_side ** 3) * 1e-3
+    assert normalised_error(kinds["auto"][0], kinds["never"][0], floor) < 1e-12
 
 
 @pytest.mark.parametrize("threads", [64, 128, 256])
