@@ -611,6 +611,13 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     if (!wide && table_fits) {
         if (g.opt_row_lanes > 0) row_lanes = static_cast<int>(g.opt_row_lanes);
         else if (g.opt_row_lanes == 0 && g.opt_p3m_lanes == 0 && lanes > 1) row_lanes = P3M_ROWS_LANES;
+        // ... and large sets once they have clustered so far that most rows a target meets are long:
+        // against the pooled kernel, 128^3 run, pair kernel alone, 4 lanes per target: a = 0.51
+        // (occupancy measure 7) 1.90 against 1.40 ms, a = 0.74 (19) 2.56 against 2.56, a = 0.84 (25)
+        // 2.84 against 3.30, a = 0.92 (32) 3.09 against 3.71 (2 lanes: 3.16 at a = 0.84, 8: 3.06)
+        else if (g.opt_row_lanes == 0 && g.opt_p3m_lanes == 0 && g.opt_p3m_pooled <= 0 &&
+                 occupancy >= P3M_ROWS_LARGE_MIN_OCCUPANCY)
+            row_lanes = P3M_ROWS_LARGE_LANES;
     }
     const bool sym = row_lanes == 0 && all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
                      n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
@@ -704,6 +711,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         const dim3 rows_grid(cdiv(static_cast<long long>(n_tgt) * row_lanes, 64)), rows_wg(64);
 #define NBPP_LAUNCH_ROWS(S0)                                                                         \
     switch (row_lanes) {                                                                             \
+        case 2: hipLaunchKernelGGL((k_p3m_rows<S0, 2>), rows_grid, rows_wg, 0, s, a); break;         \
         case 4: hipLaunchKernelGGL((k_p3m_rows<S0, 4>), rows_grid, rows_wg, 0, s, a); break;         \
         case 8: hipLaunchKernelGGL((k_p3m_rows<S0, 8>), rows_grid, rows_wg, 0, s, a); break;         \
         case 16: hipLaunchKernelGGL((k_p3m_rows<S0, 16>), rows_grid, rows_wg, 0, s, a); break;       \
@@ -903,7 +911,7 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_P3M_POOLED_DRAIN: g.opt_p3m_pooled = value; return NBPP_OK;
         case NBPP_OPT_P3M_PAIR_ONCE: g.opt_p3m_sym = value; return NBPP_OK;
         case NBPP_OPT_P3M_ROW_LANES:
-            if (value != 0 && value != -1 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
+            if (value != 0 && value != -1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
                 return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_ROW_LANES takes 0, -1, 8, 16, 32 or 64");
             g.opt_row_lanes = value;
             return NBPP_OK;

@@ -1572,10 +1572,12 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
 constexpr int P3M_ROWS_ABREAST = 2;   // rows of a target walked side by side (1, 2, 4: 0.061 / 0.058 / 0.058 ms on a
                                       // near-uniform 32^3 set, 0.089 / 0.091 / 0.099 ms on a clustered one)
 constexpr int P3M_ROWS_LANES = 8;     // lanes per target when the kernel is chosen by itself
+constexpr double P3M_ROWS_LARGE_MIN_OCCUPANCY = 22.0;   // clustering measure from which it also takes sets that fill the GPU
+constexpr int P3M_ROWS_LARGE_LANES = 4;                 // with one lane per target, and its lanes per target there
 
 template <bool SOFT0, int G>
 __global__ void __launch_bounds__(64) k_p3m_rows(const P3MArgs a) {
-    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "lanes per target");
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "lanes per target");
     constexpr int PER_WAVE = 64 / G;
     const int lane = threadIdx.x, sub = lane % G;
     const int t = static_cast<int>(blockIdx.x) * PER_WAVE + lane / G;
