@@ -131,7 +131,8 @@ def extra_p3m256(lib, ffi, torch, dev, stream, steps=6, warmup=2):
             "kernel": {0: "k_p3m_cells (every ordered pair, one lane per target)",
                        1: "k_p3m_pool (survivors pooled per wavefront)",
                        2: "k_p3m_sym (every unordered pair once, reactions gathered per brick in LDS)",
-                       3: "k_p3m_rows (the lanes of a target walk its rows together)"}[st["p3m_pooled"]],
+                       3: "k_p3m_rows (the lanes of a target walk its rows together)",
+                       4: "k_p3m_rows_pool (row walk, survivors pooled per wavefront)"}[st["p3m_pooled"]],
             "kernel_ms": k_ms,
             "prepare_ms": float(np.mean(prep_ms)),
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
@@ -447,7 +448,7 @@ def main():
         pair_shares = use_pairs if mg is None else bool(mg.stats()["pair_shares"])
         my_pairs = pairs_per_step / world if pair_shares else pairs_per_step * (counts[0] / n)
         kernel_names = {1: "k_pairs (ordered pairs)", 2: "k_pairs (per-pair wrap)",
-                        3: ["k_p3m_cells", "k_p3m_pool", "k_p3m_sym", "k_p3m_rows"][st.get("p3m_pooled", 0)],
+                        3: ["k_p3m_cells", "k_p3m_pool", "k_p3m_sym", "k_p3m_rows", "k_p3m_rows_pool"][st.get("p3m_pooled", 0)],
                         4: "k_pairs (P3M, all pairs)",
                         5: "k_pairs_sym (each unordered pair once, both directions)"}
         achieved = my_pairs * flops / (kernel_avg_ms * 1e-3) / 1e12

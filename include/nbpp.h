@@ -84,7 +84,8 @@ typedef struct nbpp_stats {
                                 wavefront (NBPP_OPT_P3M_POOLED_DRAIN), 2 if every unordered
                                 pair was evaluated once (NBPP_OPT_P3M_PAIR_ONCE), 3 if the
                                 lanes of a target walked its rows together
-                                (NBPP_OPT_P3M_ROW_LANES)                                     */
+                                (NBPP_OPT_P3M_ROW_LANES), 4 if they did and the survivors
+                                were pooled (NBPP_OPT_P3M_ROWS_POOLED)                       */
     double   cell_occupancy; /* NBPP_KERNEL_P3M_CELLS: mean over particles of the number of
                                 particles in the particle's own search cell (1 + the mean
                                 per cell when evenly spread; grows with clustering)          */
@@ -139,6 +140,12 @@ enum {
                                     are short): 0 = automatic (8 lanes, for every call that would
                                     otherwise get several lanes per target, i.e. small sets),
                                     -1 = never, else 4, 8, 16, 32 or 64                          */
+    NBPP_OPT_P3M_ROWS_POOLED = 13, /* the row walk above with the pooled kernel's drain (survivors of
+                                    a single-precision test pooled per wavefront, evaluated 64 at a
+                                    time, sums gathered per target in LDS; not reproducible):
+                                    0 = automatic (two lanes per target, for sets that fill the GPU
+                                    with one lane per target and have begun to cluster), 1 = whenever
+                                    NBPP_OPT_P3M_ROW_LANES asks for 2 to 16 lanes, -1 = never     */
     NBPP_OPT_P3M_POOL_WORKGROUP = 11 /* threads per workgroup of the pooled P3M kernel: 0 = 64, else
                                     64, 128 or 256.  Its wavefronts work independently, and alone
                                     on the GPU the kernel is 4-8 % faster with one wavefront per

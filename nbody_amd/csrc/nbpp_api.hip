@@ -145,7 +145,7 @@ struct Ctx : Work {
     int sym_skip_left = 0;
     int sym_skip_n = 0, sym_skip_nside = 0;
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
-            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0, opt_pool_wg = 0, opt_row_lanes = 0;
+            opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0, opt_pool_wg = 0, opt_row_lanes = 0, opt_rows_pooled = 0;
     nbpp_stats stats{};
 };
 
@@ -611,14 +611,23 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     if (!wide && table_fits) {
         if (g.opt_row_lanes > 0) row_lanes = static_cast<int>(g.opt_row_lanes);
         else if (g.opt_row_lanes == 0 && g.opt_p3m_lanes == 0 && lanes > 1) row_lanes = P3M_ROWS_LANES;
-        // ... and large sets once they have clustered so far that most rows a target meets are long:
-        // against the pooled kernel, 128^3 run, pair kernel alone, 4 lanes per target: a = 0.51
-        // (occupancy measure 7) 1.90 against 1.40 ms, a = 0.74 (19) 2.56 against 2.56, a = 0.84 (25)
-        // 2.84 against 3.30, a = 0.92 (32) 3.09 against 3.71 (2 lanes: 3.16 at a = 0.84, 8: 3.06)
+        // ... and large sets once nearly every row a target meets is long (the 400-blobs set, occupancy
+        // measure 442: 10.3 ms with 4 lanes per target against 12.4 with the pooled kernel)
         else if (g.opt_row_lanes == 0 && g.opt_p3m_lanes == 0 && g.opt_p3m_pooled <= 0 &&
                  occupancy >= P3M_ROWS_LARGE_MIN_OCCUPANCY)
             row_lanes = P3M_ROWS_LARGE_LANES;
     }
+    // Row walk with the pooled drain (k_p3m_rows_pool): forced (NBPP_OPT_P3M_ROWS_POOLED = 1 with a
+    // lane count from NBPP_OPT_P3M_ROW_LANES), or by itself with two lanes per target for sets that
+    // fill the GPU with one, from a clustering measure of P3M_ROWS_POOL_MIN_OCCUPANCY up to where
+    // the plain row walk takes over.  Measured on the 128^3 run, pair kernel alone, against the
+    // pooled kernel: a = 0.21 (2.8) 0.832 / 0.846 ms, a = 0.37 (3.8) 1.02 / 1.09, a = 0.51 (7.3) 1.33 /
+    // 1.41, a = 0.74 (19) 2.12 / 2.58, a = 0.89 (30) 2.75 / 3.51 (plain row walk, 4 lanes: 3.02); four
+    // lanes per target 1.49 / 2.25 / 2.79 at the last three, eight lose (few target slots, so the
+    // drain's LDS adds collide).
+    const bool rows_pool_can = !wide && table_fits && !g.opt_deterministic &&
+                               n_entries + P3M_POOL_TRIP < (1 << P3M_POOL_LANE_SHIFT);
+    bool rows_pool = rows_pool_can && g.opt_rows_pooled > 0 && row_lanes >= 2 && row_lanes <= 16;
     const bool sym = row_lanes == 0 && all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
                      n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
                      (g.opt_p3m_sym > 0 ||
@@ -629,6 +638,11 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // measure 2.6) 4.79 against 5.08 ms; the 128^3 run at a = 0.25 (2.9) 0.93 against 1.00 ms, at
     // a = 0.33 (3.4) 1.07 against 1.22, at a = 0.40 (4.4) 1.23 against 1.47, at a = 0.51 (7.3) 1.40
     // against 1.96; 400 tight blobs 12.5 against 14.8 ms.
+    if (!sym && rows_pool_can && g.opt_rows_pooled == 0 && row_lanes == 0 && g.opt_row_lanes == 0 &&
+        g.opt_p3m_lanes == 0 && g.opt_p3m_pooled == 0 && lanes == 1 && occupancy >= P3M_ROWS_POOL_MIN_OCCUPANCY) {
+        rows_pool = true;      // where the pair-once kernel does not take the call
+        row_lanes = 2;
+    }
     const bool pooled = row_lanes == 0 && lanes == 1 &&
                         (g.opt_p3m_pooled > 0 || (g.opt_p3m_pooled == 0 && !g.opt_deterministic));
 
@@ -703,6 +717,23 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         else hipLaunchKernelGGL((k_p3m_sym<false>), bricks, dim3(SYM_WG), 0, s, a, nbx, nby, nbz);
         HIPCHK(hipGetLastError());
         g.stats.p3m_pooled = 2;
+        g.stats.pairs_evaluated = 0;
+        g.stats.pair_launches = 1;
+        return NBPP_OK;
+    }
+    if (rows_pool) {
+        const dim3 rows_grid(cdiv(static_cast<long long>(n_tgt) * row_lanes, 64)), rows_wg(64);
+#define NBPP_LAUNCH_ROWS_POOL(S0)                                                                         \
+    switch (row_lanes) {                                                                                  \
+        case 2: hipLaunchKernelGGL((k_p3m_rows_pool<S0, 2>), rows_grid, rows_wg, 0, s, a); break;         \
+        case 4: hipLaunchKernelGGL((k_p3m_rows_pool<S0, 4>), rows_grid, rows_wg, 0, s, a); break;         \
+        case 8: hipLaunchKernelGGL((k_p3m_rows_pool<S0, 8>), rows_grid, rows_wg, 0, s, a); break;         \
+        default: hipLaunchKernelGGL((k_p3m_rows_pool<S0, 16>), rows_grid, rows_wg, 0, s, a); break;       \
+    }
+        if (soft0) { NBPP_LAUNCH_ROWS_POOL(true) } else { NBPP_LAUNCH_ROWS_POOL(false) }
+#undef NBPP_LAUNCH_ROWS_POOL
+        HIPCHK(hipGetLastError());
+        g.stats.p3m_pooled = 4;
         g.stats.pairs_evaluated = 0;
         g.stats.pair_launches = 1;
         return NBPP_OK;
@@ -915,6 +946,7 @@ int nbpp_set_option(int key, int64_t value) {
                 return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_ROW_LANES takes 0, -1, 8, 16, 32 or 64");
             g.opt_row_lanes = value;
             return NBPP_OK;
+        case NBPP_OPT_P3M_ROWS_POOLED: g.opt_rows_pooled = value; return NBPP_OK;
         case NBPP_OPT_P3M_POOL_WORKGROUP:
             if (value != 0 && value != 64 && value != 128 && value != 256)
                 return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_POOL_WORKGROUP takes 0, 64, 128 or 256");

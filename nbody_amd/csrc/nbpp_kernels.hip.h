@@ -1572,7 +1572,8 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
 constexpr int P3M_ROWS_ABREAST = 2;   // rows of a target walked side by side (1, 2, 4: 0.061 / 0.058 / 0.058 ms on a
                                       // near-uniform 32^3 set, 0.089 / 0.091 / 0.099 ms on a clustered one)
 constexpr int P3M_ROWS_LANES = 8;     // lanes per target when the kernel is chosen by itself
-constexpr double P3M_ROWS_LARGE_MIN_OCCUPANCY = 22.0;   // clustering measure from which it also takes sets that fill the GPU
+constexpr double P3M_ROWS_LARGE_MIN_OCCUPANCY = 64.0;   // clustering measure from which it also takes sets that fill the GPU
+constexpr double P3M_ROWS_POOL_MIN_OCCUPANCY = 2.7;     // ... and from which k_p3m_rows_pool takes them below that
 constexpr int P3M_ROWS_LARGE_LANES = 4;                 // with one lane per target, and its lanes per target there
 
 template <bool SOFT0, int G>
@@ -1667,6 +1668,151 @@ __global__ void __launch_bounds__(64) k_p3m_rows(const P3MArgs a) {
         unsigned long long h = live ? hits : 0u;
         for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
         if (lane == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Row walk and pooled evaluation together.
+//
+// k_p3m_rows evaluates a candidate in the lane that tested it: where four candidates in ten pass
+// the exact test, six lanes in ten sit out the 67 issue slots of the arithmetic.  Here the G lanes
+// of a target walk its (trimmed) rows as there - lane `sub` takes four consecutive candidates at
+// sub * 4, (sub + G) * 4, ... of a row, tested in single precision on the packed fp32 coordinates
+// - and the survivors go into the wavefront's ring as (target slot, source) pairs, to be
+// evaluated 64 at a time by whatever lane, the sums gathered per target in LDS with ds_add_f64:
+// the drain of k_p3m_pool.  Not bitwise reproducible (colliding adds land in hardware order).
+// ---------------------------------------------------------------------------------
+template <bool SOFT0, int G>
+__global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per target");
+    constexpr int PER_WAVE = 64 / G;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    __shared__ unsigned ring[P3M_POOL_CAP];
+    __shared__ double2 txy[PER_WAVE];
+    __shared__ double tz[PER_WAVE];
+    __shared__ double tsum[3][PER_WAVE];
+    const int lane = threadIdx.x, sub = lane % G, slot = lane / G;
+    const int t = static_cast<int>(blockIdx.x) * PER_WAVE + slot;
+    const bool live = t < a.n_tgt;
+    const int p = a.tlist[live ? t : a.n_tgt - 1];
+    const double4 me = a.rec[p];
+    const vf4 nmx = -a.fx[p], nmy = -a.fy[p], nmz = -a.fz[p];   // splats
+    const GhostGrid g = a.g;
+    const PairConsts k = a.k;
+    const float bound = a.prefilter_sq;
+    const int pcx = bin_coord(me.x, g.scale, g.nside) + g.R;
+    const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
+    const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
+    if (sub == 0) {
+        txy[slot] = make_double2(me.x, me.y);
+        tz[slot] = me.z;
+        tsum[0][slot] = 0.0;
+        tsum[1][slot] = 0.0;
+        tsum[2][slot] = 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();   // one wavefront: its LDS operations stay in order
+    int rp = 0, wp = 0;                // ring read / write positions, unwrapped, the same in every lane
+    unsigned hits = 0;
+    const uint32_t f_bytes = static_cast<uint32_t>(a.n_entries + P3M_POOL_TRIP) << 2;
+    const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fz), 0, f_bytes, 0x00020000);
+    const uint32_t rec_bytes = static_cast<uint32_t>(a.n_entries) << 5;
+    const __amdgpu_buffer_rsrc_t rec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
+
+    // one drain step: NB * 64 pairs from the front of the ring, NB per lane in flight together
+    auto drain = [&](auto nb_tag, int count) {
+        constexpr int NB = decltype(nb_tag)::value;
+        unsigned ts[NB], sj[NB];      // target slot, source
+        bool valid[NB];
+        double4 s[NB];
+        double2 gxy[NB];
+        double gz[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            valid[u] = u * 64 + lane < count;
+            const unsigned e = ring[(rp + u * 64 + lane) & (P3M_POOL_CAP - 1)];
+            ts[u] = valid[u] ? e >> P3M_POOL_LANE_SHIFT : static_cast<unsigned>(slot);
+            sj[u] = valid[u] ? e & ((1u << P3M_POOL_LANE_SHIFT) - 1u) : static_cast<unsigned>(p);
+            gxy[u] = txy[ts[u]];
+            gz[u] = tz[ts[u]];
+            s[u] = load_record_checked(rec_rsrc, valid[u] ? sj[u] << 5 : 0xffffffe0u);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const double dx = s[u].x - gxy[u].x, dy = s[u].y - gxy[u].y, dz = s[u].z - gz[u];
+            const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+            if (valid[u] && !(r2 > k.cutoff_sq)) {   // the reference's cutoff test (src/particles.cpp:326)
+                double cx = 0.0, cy = 0.0, cz = 0.0;
+                p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, cx, cy, cz);
+                __hip_atomic_fetch_add(&tsum[0][ts[u]], cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&tsum[1][ts[u]], cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&tsum[2][ts[u]], cz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ++hits;
+            }
+        }
+        rp += min(count, NB * 64);
+    };
+
+    const int span = 2 * g.R + 1;
+    const int n_rows = span * span;
+    const RowTrim trim = make_row_trim(me, pcx, pcy, pcz, g, k);
+    const StartTable<true> starts = make_start_table<true>(a.cell_start, g);
+    int nj = 0, nje = 0;
+    auto request_row = [&](int row) {
+        const int ox = row / span, oy = row - ox * span;
+        int zlo = 0, zhi = 0;
+        const bool reach = row_window(trim, ox - g.R, oy - g.R, g.R, zlo, zhi);
+        const bool has = live && row < n_rows && reach;
+        const int base = ((pcx - g.R + ox) * g.np + (pcy - g.R + oy)) * g.np + pcz;
+        nj = load_start(starts, base + zlo, has);
+        nje = load_start(starts, base + zhi + 1, has);
+    };
+    request_row(0);
+    const unsigned tag = static_cast<unsigned>(slot) << P3M_POOL_LANE_SHIFT;
+#pragma unroll 1
+    for (int row = 0; row < n_rows; ++row) {
+        int j = nj + 4 * sub;
+        const int je = nje;
+        request_row(row + 1);          // in flight while this row is walked
+#pragma unroll 1
+        while (__any(j < je)) {
+            const uint32_t off = j < je ? static_cast<uint32_t>(j) << 2 : 0xfffffff0u;
+            const vf4 cx = p3m_fvec_load<4>::get(fx_rsrc, off);
+            const vf4 cy = p3m_fvec_load<4>::get(fy_rsrc, off);
+            const vf4 cz = p3m_fvec_load<4>::get(fz_rsrc, off);
+            const vf4 dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
+            const vf4 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+            const int left = je - j;
+            const unsigned entry0 = tag | static_cast<unsigned>(j);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in_run = u < left, near = !(r2[u] > bound);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(in_run) & __builtin_amdgcn_ballot_w64(near);
+                const int at = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), static_cast<unsigned>(wp)));
+                if (in_run & near) ring[at & (P3M_POOL_CAP - 1)] = entry0 + static_cast<unsigned>(u);
+                wp += __popcll(m);
+            }
+            // at most 127 left + 4 * 64 new entries in a ring of 512
+            while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, 128);
+            j += 4 * G;
+        }
+    }
+    while (wp - rp > 0) drain(std::integral_constant<int, 1>{}, wp - rp);
+    __builtin_amdgcn_wave_barrier();
+    if (live && sub == 0) {
+        const int o = a.entries[p] - a.tgt_begin;
+        a.ax[o] += tsum[0][slot];
+        a.ay[o] += tsum[1][slot];
+        a.az[o] += tsum[2][slot];
+    }
+    if (a.accepted) {
+        // pairs are counted by the lane that evaluated them; every live target met itself once
+        long long h = static_cast<long long>(hits) - ((live && sub == 0) ? 1 : 0);
+        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        if (lane == 0 && h) atomicAdd(accepted_stripe(a.accepted), static_cast<unsigned long long>(h));
     }
 }
 

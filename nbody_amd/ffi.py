@@ -17,6 +17,7 @@ NOALLOC_SCRATCH_BYTES = 48 * 1024 * 1024  # NBPP_NOALLOC_SCRATCH_BYTES
 OPT_FORCE_KERNEL, OPT_TIMING, OPT_TARGETS_PER_LANE, OPT_SOURCE_SPLIT, OPT_P3M_SEARCH_RADIUS, \
     OPT_NO_EQUAL_MASS_PATH, OPT_DETERMINISTIC, OPT_P3M_LANES_PER_TARGET, OPT_P3M_POOLED_DRAIN, OPT_P3M_PAIR_ONCE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 OPT_P3M_ROW_LANES = 12        # lanes of one target walking every row together: 0 automatic, -1 never, 4 / 8 / 16 / 32 / 64
+OPT_P3M_ROWS_POOLED = 13      # the row walk with the pooled drain: 0 automatic, 1 with OPT_P3M_ROW_LANES 2..16, -1 never
 OPT_P3M_POOL_WORKGROUP = 11   # threads per workgroup of the pooled P3M kernel: 0 = 64, else 64, 128 or 256
 
 EXPORTS = (

@@ -152,11 +152,16 @@ bool DeviceEngine::launch_short_range() {
     // hardly ever find room (1.69 against 1.57 ms per cycle at 128^3).  Once the particles have
     // clustered the pair kernel outlasts the mesh and gas work several times over and runs mostly
     // alone: one wavefront per workgroup from a clustering measure of 4 on (1 % over the first 16 000
-    // cycles of the 128^3 run, which end at a = 0.55).
-    nbpp_check(nbpp_set_option(NBPP_OPT_P3M_POOL_WORKGROUP, last_occupancy_ >= 4.0 ? 64 : 256));
+    // cycles of the 128^3 run, which end at a = 0.55).  The same goes for the row walk with the pooled
+    // drain, whose workgroups are single wavefronts: kept out of the lightly clustered cycles (1.58
+    // against 1.52 ms per cycle over the first 100), the library's own choice afterwards.
+    const bool alone = last_occupancy_ >= 4.0;
+    nbpp_check(nbpp_set_option(NBPP_OPT_P3M_POOL_WORKGROUP, alone ? 64 : 256));
+    nbpp_check(nbpp_set_option(NBPP_OPT_P3M_ROWS_POOLED, alone ? 0 : -1));   // its workgroups are single wavefronts too
     nbpp_check(nbpp_accumulate_device(&p, n_, dev_[0], dev_[1], dev_[2], dev_[9], 0, n_, pp_acc_[0], pp_acc_[1],
                                       pp_acc_[2], pp_stream_));
     nbpp_check(nbpp_set_option(NBPP_OPT_P3M_POOL_WORKGROUP, 0));
+    nbpp_check(nbpp_set_option(NBPP_OPT_P3M_ROWS_POOLED, 0));
     nbpp_stats st;
     if (nbpp_get_stats(&st) == NBPP_OK) last_occupancy_ = st.cell_occupancy;
     hip_check(hipEventRecord(static_cast<hipEvent_t>(ev_pp_), pps), "event");

@@ -972,6 +972,79 @@ def test_p3m_lanes_walking_rows_together(lib, oracle, name, row_lanes):
     assert normalised_error([a[:n_tgt] for a in got], want, pair_force_scale(p, m, n) * 1e-3) < TOL
 
 
+@pytest.mark.parametrize("row_lanes", [2, 4, 8, 16])
+@pytest.mark.parametrize("name", ["clustered", "lattice_soft0"])
+def test_p3m_row_walk_with_pooled_drain(lib, oracle, name, row_lanes):
+    """k_p3m_rows_pool (NBPP_OPT_P3M_ROWS_POOLED = 1 with 2 to 16 lanes per target): the row walk
+    with a single-precision test, survivors pooled per wavefront and evaluated 64 at a time.  Exact
+    accepted-pair count against the oracle (every target also meets itself once, which is taken out
+    again), sums within the parity bar; ragged target count, unequal masses, cells holding hundreds
+    of particles; zero softening on a lattice."""
+    n_side = 28
+    n = n_side ** 3 - 11
+    if name == "clustered":
+        pos = datasets.clustered(n, n_blobs=9, sigma=0.02, seed=5)
+        m = datasets.masses(n, equal=False)
+    else:
+        pos = [c[:n].copy() for c in datasets.jittered_lattice(n_side, jitter=0.9)]
+        m = datasets.masses(n, equal=True)
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    if name == "lattice_soft0":
+        config.SOFTENING_SQUARED = 0.0
+    p = config.pp_params()
+    try:
+        lib.set_option(ffi.OPT_P3M_ROW_LANES, row_lanes)
+        lib.set_option(ffi.OPT_P3M_ROWS_POOLED, 1)
+        got = gpu_acc(lib, p, pos, m)
+        st = lib.stats()
+    finally:
+        lib.set_option(ffi.OPT_P3M_ROW_LANES, 0)
+        lib.set_option(ffi.OPT_P3M_ROWS_POOLED, 0)
+    assert st["kernel_variant"] == ffi.KERNEL_P3M_CELLS and st["p3m_pooled"] == 4
+    assert st["pairs_accepted"] == oracle.count_within_cutoff(p, *pos)
+    n_tgt = 3000
+    want = oracle.accumulate(p, *pos, m, tgt_begin=0, n_tgt=n_tgt, traversal=O.EXACT_CELLS)
+    assert normalised_error([a[:n_tgt] for a in got], want, pair_force_scale(p, m, n) * 1e-3) < TOL
+
+
+def test_large_clustering_set_gets_the_row_walk_with_pooled_drain(lib, oracle):
+    """A set that fills the GPU with one lane per target and has begun to cluster (clustering
+    measure above 2.7, no brick of cells the pair-once kernel could hold) is given k_p3m_rows_pool
+    with two lanes per target; NBPP_OPT_P3M_ROWS_POOLED = -1 keeps the pooled kernel.  Same exact
+    count, sums equal to rounding, sampled targets against the oracle."""
+    import torch
+    n_side = 112
+    n = n_side ** 3
+    pos = datasets.clustered(n, n_blobs=1500, sigma=0.02, seed=8)
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    m = np.full(n, config.DM_PARTICLE_MASS)
+    p = config.pp_params()
+    dev = _t(pos + [m])
+    out = {}
+    try:
+        for label, value in (("auto", 0), ("never", -1)):
+            lib.set_option(ffi.OPT_P3M_ROWS_POOLED, value)
+            lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0 if label == "auto" else 1)
+            acc = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+            lib.accumulate_device(p, *dev, *acc)
+            torch.cuda.synchronize()
+            st = lib.stats()
+            out[label] = ([a.cpu().numpy() for a in acc], st["p3m_pooled"], st["pairs_accepted"], st["cell_occupancy"])
+    finally:
+        lib.set_option(ffi.OPT_P3M_ROWS_POOLED, 0)
+        lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
+    occupancy = out["auto"][3]
+    assert 2.7 <= occupancy < 64.0 and n >= 65536 * min(occupancy, 16.0), occupancy   # what the data set is meant to be
+    assert out["auto"][1] == 4
+    assert out["never"][1] == 1
+    assert out["auto"][2] == out["never"][2]
+    floor = pair_force_scale(p, m, n) * 1e-3
+    assert normalised_error(out["auto"][0], out["never"][0], floor) < 1e-11
+    begin = n // 3
+    want = oracle.accumulate(p, *pos, m, tgt_begin=begin, n_tgt=16, traversal=O.EXACT_CELLS)
+    assert normalised_error([g[begin:begin + 16] for g in out["auto"][0]], want, floor) < TOL
+
+
 def test_small_sets_get_the_row_walking_kernel_by_themselves(lib, oracle):
     """A set small enough to get several lanes per target is given k_p3m_rows; a forced lane count
     (NBPP_OPT_P3M_LANES_PER_TARGET) or NBPP_OPT_P3M_ROW_LANES = -1 keeps k_p3m_cells."""
