@@ -1411,7 +1411,7 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
     tsum[2][threadIdx.x] = 0.0;
     __builtin_amdgcn_wave_barrier();   // only this wavefront reads them back, and LDS operations of a wavefront stay in order
     int rp = 0, wp = 0;                // ring read / write positions, unwrapped, the same in every lane
-    unsigned hits = 0;
+    unsigned hits = 0;                 // accepted pairs of the wavefront (the same in every lane)
     const uint32_t f_bytes = WIDE ? 0u : static_cast<uint32_t>(a.n_entries + P3M_POOL_TRIP) << 2;
     const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
@@ -1425,8 +1425,10 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
     // own record passes the filter once: its displacement is exactly zero, so it adds exactly
     // zero to the sums (with zero softening p3m_accepted returns 0 for r = 0); it is taken out of
     // the pair count at the end.
-    auto drain = [&](auto nb_tag, int count) {
+    // FULL: the step takes NB * 64 entries, every lane has NB pairs.
+    auto drain = [&](auto nb_tag, auto full_tag, int count) {
         constexpr int NB = decltype(nb_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
         unsigned tl[NB], sj[NB];      // target lane, source
         bool valid[NB];
         double4 s[NB];
@@ -1434,7 +1436,7 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
         double gz[NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            valid[u] = u * 64 + lane < count;
+            valid[u] = FULL || u * 64 + lane < count;
             const Entry e = ring[(rp + u * 64 + lane) & (P3M_POOL_CAP - 1)];
             if constexpr (WIDE) {
                 tl[u] = valid[u] ? e.x : static_cast<unsigned>(lane);
@@ -1452,17 +1454,18 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
         for (int u = 0; u < NB; ++u) {
             const double dx = s[u].x - gxy[u].x, dy = s[u].y - gxy[u].y, dz = s[u].z - gz[u];
             const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-            if (valid[u] && !(r2 > k.cutoff_sq)) {   // the reference's cutoff test (src/particles.cpp:326)
+            const bool accept = valid[u] && !(r2 > k.cutoff_sq);   // the reference's cutoff test (src/particles.cpp:326)
+            hits += __popcll(__builtin_amdgcn_ballot_w64(accept));   // counted on the scalar side
+            if (accept) {
                 double cx = 0.0, cy = 0.0, cz = 0.0;
                 p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, cx, cy, cz);
                 const int slot = wave_base + static_cast<int>(tl[u]);
                 __hip_atomic_fetch_add(&tsum[0][slot], cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&tsum[1][slot], cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&tsum[2][slot], cz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ++hits;
             }
         }
-        rp += min(count, NB * 64);
+        rp += FULL ? NB * 64 : min(count, NB * 64);
     };
 
     const int span = 2 * g.R + 1;
@@ -1525,11 +1528,11 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
             if (in_run & near) ring[at & (P3M_POOL_CAP - 1)] = entry;
             wp += __popcll(m);
             if (u % 4 == 3)       // at most 127 left + 4 * 64 new entries in a ring of 512
-                while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, 128);
+                while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, std::true_type{}, 128);
         }
         j += P3M_POOL_TRIP;
     }
-    while (wp - rp > 0) drain(std::integral_constant<int, 1>{}, wp - rp);
+    while (wp - rp > 0) drain(std::integral_constant<int, 1>{}, std::false_type{}, wp - rp);
     __builtin_amdgcn_wave_barrier();
 
     if (live) {
@@ -1539,9 +1542,8 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
         a.az[o] += tsum[2][threadIdx.x];
     }
     if (a.accepted) {
-        // pairs are counted by the lane that evaluated them; every live target met itself once
-        long long h = static_cast<long long>(hits) - (live ? 1 : 0);
-        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        // every live target met itself once
+        const long long h = static_cast<long long>(hits) - __popcll(__builtin_amdgcn_ballot_w64(live));
         if (lane == 0 && h) atomicAdd(accepted_stripe(a.accepted), static_cast<unsigned long long>(h));
     }
 }
@@ -1712,7 +1714,7 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
     }
     __builtin_amdgcn_wave_barrier();   // one wavefront: its LDS operations stay in order
     int rp = 0, wp = 0;                // ring read / write positions, unwrapped, the same in every lane
-    unsigned hits = 0;
+    unsigned hits = 0;                 // accepted pairs of the wavefront (the same in every lane)
     const uint32_t f_bytes = static_cast<uint32_t>(a.n_entries + P3M_POOL_TRIP) << 2;
     const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
@@ -1722,8 +1724,10 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
 
     // one drain step: NB * 64 pairs from the front of the ring, NB per lane in flight together
-    auto drain = [&](auto nb_tag, int count) {
+    // FULL: the step takes NB * 64 entries, every lane has NB pairs.
+    auto drain = [&](auto nb_tag, auto full_tag, int count) {
         constexpr int NB = decltype(nb_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
         unsigned ts[NB], sj[NB];      // target slot, source
         bool valid[NB];
         double4 s[NB];
@@ -1731,8 +1735,11 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
         double gz[NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            valid[u] = u * 64 + lane < count;
-            const unsigned e = ring[(rp + u * 64 + lane) & (P3M_POOL_CAP - 1)];
+            // a lane takes NB consecutive entries: a target's survivors lie together in the ring, and spread
+            // over the NB evaluations fewer of one evaluation's adds meet at the same sum
+            const int at = lane * NB + u;
+            valid[u] = FULL || at < count;
+            const unsigned e = ring[(rp + at) & (P3M_POOL_CAP - 1)];
             ts[u] = valid[u] ? e >> P3M_POOL_LANE_SHIFT : static_cast<unsigned>(slot);
             sj[u] = valid[u] ? e & ((1u << P3M_POOL_LANE_SHIFT) - 1u) : static_cast<unsigned>(p);
             gxy[u] = txy[ts[u]];
@@ -1743,16 +1750,17 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
         for (int u = 0; u < NB; ++u) {
             const double dx = s[u].x - gxy[u].x, dy = s[u].y - gxy[u].y, dz = s[u].z - gz[u];
             const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-            if (valid[u] && !(r2 > k.cutoff_sq)) {   // the reference's cutoff test (src/particles.cpp:326)
+            const bool accept = valid[u] && !(r2 > k.cutoff_sq);   // the reference's cutoff test (src/particles.cpp:326)
+            hits += __popcll(__builtin_amdgcn_ballot_w64(accept));   // counted on the scalar side
+            if (accept) {
                 double cx = 0.0, cy = 0.0, cz = 0.0;
                 p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, cx, cy, cz);
                 __hip_atomic_fetch_add(&tsum[0][ts[u]], cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&tsum[1][ts[u]], cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&tsum[2][ts[u]], cz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ++hits;
             }
         }
-        rp += min(count, NB * 64);
+        rp += FULL ? NB * 64 : min(count, NB * 64);
     };
 
     const int span = 2 * g.R + 1;
@@ -1796,11 +1804,11 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
                 wp += __popcll(m);
             }
             // at most 127 left + 4 * 64 new entries in a ring of 512
-            while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, 128);
+            while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, std::true_type{}, 128);
             j += 4 * G;
         }
     }
-    while (wp - rp > 0) drain(std::integral_constant<int, 1>{}, wp - rp);
+    while (wp - rp > 0) drain(std::integral_constant<int, 1>{}, std::false_type{}, wp - rp);
     __builtin_amdgcn_wave_barrier();
     if (live && sub == 0) {
         const int o = a.entries[p] - a.tgt_begin;
@@ -1809,9 +1817,8 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
         a.az[o] += tsum[2][slot];
     }
     if (a.accepted) {
-        // pairs are counted by the lane that evaluated them; every live target met itself once
-        long long h = static_cast<long long>(hits) - ((live && sub == 0) ? 1 : 0);
-        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        // every live target met itself once
+        const long long h = static_cast<long long>(hits) - __popcll(__builtin_amdgcn_ballot_w64(live && sub == 0));
         if (lane == 0 && h) atomicAdd(accepted_stripe(a.accepted), static_cast<unsigned long long>(h));
     }
 }
