@@ -1681,7 +1681,7 @@ __global__ void __launch_bounds__(64) k_p3m_rows(const P3MArgs a) {
 // of a target walk its (trimmed) rows as there - lane `sub` takes four consecutive candidates at
 // sub * 4, (sub + G) * 4, ... of a row, tested in single precision on the packed fp32 coordinates
 // - and the survivors go into the wavefront's ring as (target slot, source) pairs, to be
-// evaluated 64 at a time by whatever lane, the sums gathered per target in LDS with ds_add_f64:
+// evaluated 128 at a time by whatever lane, the sums gathered per target in LDS with ds_add_f64:
 // the drain of k_p3m_pool.  Not bitwise reproducible (colliding adds land in hardware order).
 // ---------------------------------------------------------------------------------
 template <bool SOFT0, int G>
@@ -1689,9 +1689,12 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per target");
     constexpr int PER_WAVE = 64 / G;
     typedef float vf4 __attribute__((ext_vector_type(4)));
-    __shared__ unsigned ring[P3M_POOL_CAP];
-    __shared__ double2 txy[PER_WAVE];
-    __shared__ double tz[PER_WAVE];
+    // ring entry = target slot << 27 | sorted position of the source (< 2^26): shifted left by five, to the
+    // byte offset of the source's record, the slot is gone
+    constexpr int SLOT_SHIFT = 27;
+    struct Target { double2 xy; double z, pad; };      // one LDS address serves both reads
+    __shared__ __align__(8) unsigned ring[P3M_POOL_CAP];
+    __shared__ Target txyz[PER_WAVE];
     __shared__ double tsum[3][PER_WAVE];
     const int lane = threadIdx.x, sub = lane % G, slot = lane / G;
     const int t = static_cast<int>(blockIdx.x) * PER_WAVE + slot;
@@ -1706,8 +1709,8 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
     const int pcy = bin_coord(me.y, g.scale, g.nside) + g.R;
     const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
     if (sub == 0) {
-        txy[slot] = make_double2(me.x, me.y);
-        tz[slot] = me.z;
+        txyz[slot].xy = make_double2(me.x, me.y);
+        txyz[slot].z = me.z;
         tsum[0][slot] = 0.0;
         tsum[1][slot] = 0.0;
         tsum[2][slot] = 0.0;
@@ -1728,23 +1731,28 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
     auto drain = [&](auto nb_tag, auto full_tag, int count) {
         constexpr int NB = decltype(nb_tag)::value;
         constexpr bool FULL = decltype(full_tag)::value;
-        unsigned ts[NB], sj[NB];      // target slot, source
+        unsigned ts[NB], en[NB];      // target slot, ring entry
         bool valid[NB];
         double4 s[NB];
         double2 gxy[NB];
         double gz[NB];
+        // a lane takes NB consecutive entries: a target's survivors lie together in the ring, and spread
+        // over the NB evaluations fewer of one evaluation's adds meet at the same sum
+        if constexpr (FULL && NB == 2) {   // full steps leave rp even: one 8-byte read, which does not wrap
+            const uint2 both = *reinterpret_cast<const uint2*>(&ring[(rp + 2 * lane) & (P3M_POOL_CAP - 1)]);
+            en[0] = both.x;
+            en[1] = both.y;
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) en[u] = ring[(rp + lane * NB + u) & (P3M_POOL_CAP - 1)];
+        }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            // a lane takes NB consecutive entries: a target's survivors lie together in the ring, and spread
-            // over the NB evaluations fewer of one evaluation's adds meet at the same sum
-            const int at = lane * NB + u;
-            valid[u] = FULL || at < count;
-            const unsigned e = ring[(rp + at) & (P3M_POOL_CAP - 1)];
-            ts[u] = valid[u] ? e >> P3M_POOL_LANE_SHIFT : static_cast<unsigned>(slot);
-            sj[u] = valid[u] ? e & ((1u << P3M_POOL_LANE_SHIFT) - 1u) : static_cast<unsigned>(p);
-            gxy[u] = txy[ts[u]];
-            gz[u] = tz[ts[u]];
-            s[u] = load_record_checked(rec_rsrc, valid[u] ? sj[u] << 5 : 0xffffffe0u);
+            valid[u] = FULL || lane * NB + u < count;
+            ts[u] = valid[u] ? en[u] >> SLOT_SHIFT : static_cast<unsigned>(slot);
+            gxy[u] = txyz[ts[u]].xy;
+            gz[u] = txyz[ts[u]].z;
+            s[u] = load_record_checked(rec_rsrc, valid[u] ? en[u] << 5 : 0xffffffe0u);
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -1778,7 +1786,7 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
         nje = load_start(starts, base + zhi + 1, has);
     };
     request_row(0);
-    const unsigned tag = static_cast<unsigned>(slot) << P3M_POOL_LANE_SHIFT;
+    const unsigned tag = static_cast<unsigned>(slot) << SLOT_SHIFT;
 #pragma unroll 1
     for (int row = 0; row < n_rows; ++row) {
         int j = nj + 4 * sub;
