@@ -28,7 +28,7 @@ def main():
     dom = [r for r in summary["kernel_stats"] if pick in r["name"]]
     summary["dominant"] = dom[0] if dom else None
     counters = {}
-    for name in ("pmc_valu", "pmc_wait", "pmc_fetch", "pmc_write"):
+    for name in ("pmc_valu", "pmc_wait", "pmc_mem", "pmc_fetch", "pmc_write"):
         f = find(profdir, name, "_counter_collection.csv")
         if not f:
             continue
