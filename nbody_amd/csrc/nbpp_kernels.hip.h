@@ -1208,7 +1208,7 @@ __global__ void __launch_bounds__(P3M_CELLS_WG) k_p3m_cells(const P3MArgs a) {
     double ax = 0.0, ay = 0.0, az = 0.0;
     int rp = 0, wp = 0;   // ring read / write positions, unwrapped: wp - rp entries are queued
     int lim = P3M_QCAP - P3M_TRIP;   // the filter stops for a drain once some lane's wp exceeds it
-    unsigned hits = 0;
+    unsigned long long hits = 0;
     // the arrays are P3M_TRIP values longer than n_entries, so a vector that starts at a valid
     // entry lies inside the range check.  WIDE: byte offsets may not fit 32 bits; plain pointer
     // loads then, exhausted lanes pointed at their own record.
@@ -1241,10 +1241,9 @@ __global__ void __launch_bounds__(P3M_CELLS_WG) k_p3m_cells(const P3MArgs a) {
             for (int u = 0; u < DU; ++u) {
                 const double dx = s[u].x - me.x, dy = s[u].y - me.y, dz = s[u].z - me.z;
                 const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-                if (valid[u] && !(r2 > k.cutoff_sq)) {
-                    p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, ax, ay, az);
-                    ++hits;
-                }
+                const bool accept = valid[u] && !(r2 > k.cutoff_sq);
+                hits += __popcll(__builtin_amdgcn_ballot_w64(accept));   // the wavefront's count, kept on the scalar side
+                if (accept) p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, ax, ay, az);
             }
         }
         rp += min(quota, cnt);
@@ -1338,8 +1337,7 @@ __global__ void __launch_bounds__(P3M_CELLS_WG) k_p3m_cells(const P3MArgs a) {
         a.ax[o] += ax; a.ay[o] += ay; a.az[o] += az;
     }
     if (a.accepted) {
-        unsigned long long h = live ? hits : 0u;
-        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        const unsigned long long h = hits;
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
     }
 }
@@ -1411,7 +1409,7 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
     tsum[2][threadIdx.x] = 0.0;
     __builtin_amdgcn_wave_barrier();   // only this wavefront reads them back, and LDS operations of a wavefront stay in order
     int rp = 0, wp = 0;                // ring read / write positions, unwrapped, the same in every lane
-    unsigned hits = 0;                 // accepted pairs of the wavefront (the same in every lane)
+    unsigned long long hits = 0;                 // accepted pairs of the wavefront (the same in every lane)
     const uint32_t f_bytes = WIDE ? 0u : static_cast<uint32_t>(a.n_entries + P3M_POOL_TRIP) << 2;
     const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
@@ -1598,7 +1596,7 @@ __global__ void __launch_bounds__(64) k_p3m_rows(const P3MArgs a) {
     const __amdgpu_buffer_rsrc_t rec_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
     double ax = 0.0, ay = 0.0, az = 0.0;
-    unsigned hits = 0;
+    unsigned long long hits = 0;
     const int span = 2 * g.R + 1;
     const int n_rows = span * span;
     // bounds of the part of row `row` this target can reach (none for a padding lane or past the last row)
@@ -1614,10 +1612,9 @@ __global__ void __launch_bounds__(64) k_p3m_rows(const P3MArgs a) {
     auto candidate = [&](const double4& s, bool valid, int j) {
         const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
         const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-        if (valid && j != p && !(r2 > k.cutoff_sq)) {      // the reference's cutoff test (src/particles.cpp:326)
-            p3m_accepted<SOFT0>(dx, dy, dz, r2, s.w, k, ax, ay, az);
-            ++hits;
-        }
+        const bool accept = valid && j != p && !(r2 > k.cutoff_sq);   // the reference's cutoff test (src/particles.cpp:326)
+        hits += __popcll(__builtin_amdgcn_ballot_w64(accept));        // the wavefront's count, kept on the scalar side
+        if (accept) p3m_accepted<SOFT0>(dx, dy, dz, r2, s.w, k, ax, ay, az);
     };
     // ROWS rows are walked side by side, two candidates of each per trip: most rows of a small set
     // are a handful of candidates long, and one row at a time the kernel does little but wait for
@@ -1667,8 +1664,7 @@ __global__ void __launch_bounds__(64) k_p3m_rows(const P3MArgs a) {
         a.ax[o] += ax; a.ay[o] += ay; a.az[o] += az;
     }
     if (a.accepted) {
-        unsigned long long h = live ? hits : 0u;
-        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        const unsigned long long h = hits;
         if (lane == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
     }
 }
@@ -1717,7 +1713,7 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
     }
     __builtin_amdgcn_wave_barrier();   // one wavefront: its LDS operations stay in order
     int rp = 0, wp = 0;                // ring read / write positions, unwrapped, the same in every lane
-    unsigned hits = 0;                 // accepted pairs of the wavefront (the same in every lane)
+    unsigned long long hits = 0;                 // accepted pairs of the wavefront (the same in every lane)
     const uint32_t f_bytes = static_cast<uint32_t>(a.n_entries + P3M_POOL_TRIP) << 2;
     const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
@@ -1806,9 +1802,13 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
             for (int u = 0; u < 4; ++u) {
                 const bool in_run = u < left, near = !(r2[u] > bound);
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(in_run) & __builtin_amdgcn_ballot_w64(near);
-                const int at = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), static_cast<unsigned>(wp)));
-                if (in_run & near) ring[at & (P3M_POOL_CAP - 1)] = entry0 + static_cast<unsigned>(u);
+                // byte address in the ring: the rank among this slot's survivors, times four, on the scalar
+                // side's wrapped write position
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
+                const unsigned at = ((rank << 2) + ((static_cast<unsigned>(wp) & (P3M_POOL_CAP - 1)) << 2)) & (4 * P3M_POOL_CAP - 4);
+                if (in_run & near)
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ring) + at) = entry0 + static_cast<unsigned>(u);
                 wp += __popcll(m);
             }
             // at most 127 left + 4 * 64 new entries in a ring of 512
@@ -2007,7 +2007,7 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
     const int span = 2 * g.R + 1;
     const int n_rows = g.R * span + g.R + 1;     // the own row, then every row after it in (x, y) order
     const StartTable<true> starts = make_start_table<true>(a.cell_start, g);
-    unsigned hits = 0;
+    unsigned long long hits = 0;
     constexpr int DU = SYM_DU;
 
 #pragma unroll 1
@@ -2048,7 +2048,9 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
                 for (int u = 0; u < DU; ++u) {
                     const double dx = s[u].x - me.x, dy = s[u].y - me.y, dz = s[u].z - me.z;
                     const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-                    if (valid[u] && !(r2 > k.cutoff_sq)) {     // src/particles.cpp:326
+                    const bool accept = valid[u] && !(r2 > k.cutoff_sq);     // src/particles.cpp:326
+                    hits += __popcll(__builtin_amdgcn_ballot_w64(accept));   // the wavefront's count, kept on the scalar side
+                    if (accept) {
                         const double f = p3m_factor<SOFT0>(r2, k);
                         const double fx = f * dx, fy = f * dy, fz = f * dz;
                         ax = __builtin_fma(s[u].w, fx, ax);    // a_i += G m_j f d
@@ -2058,7 +2060,6 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
                         __hip_atomic_fetch_add(&acc[0][slot[u]], ngm * fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(&acc[1][slot[u]], ngm * fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(&acc[2][slot[u]], ngm * fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        ++hits;
                     }
                 }
             }
@@ -2176,8 +2177,7 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
         }
     }
     if (a.accepted) {
-        unsigned long long h = 2ull * hits;          // both members of every pair
-        for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);
+        const unsigned long long h = 2ull * hits;    // both members of every pair
         if ((tid & 63) == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
     }
 }
