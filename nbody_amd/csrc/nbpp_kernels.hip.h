@@ -1241,7 +1241,7 @@ __global__ void __launch_bounds__(P3M_CELLS_WG) k_p3m_cells(const P3MArgs a) {
             for (int u = 0; u < DU; ++u) {
                 const double dx = s[u].x - me.x, dy = s[u].y - me.y, dz = s[u].z - me.z;
                 const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-                const bool accept = valid[u] && !(r2 > k.cutoff_sq);
+                const bool accept = live && valid[u] && !(r2 > k.cutoff_sq);   // (padding lanes walk the last target's rows)
                 hits += __popcll(__builtin_amdgcn_ballot_w64(accept));   // the wavefront's count, kept on the scalar side
                 if (accept) p3m_accepted<SOFT0>(dx, dy, dz, r2, s[u].w, k, ax, ay, az);
             }
@@ -1518,12 +1518,15 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
             const bool in_run = u < left, near = !(r2[u] > bound);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(in_run) & __builtin_amdgcn_ballot_w64(near);
             // the survivors of this slot go to consecutive ring entries in lane order
-            const int at = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), static_cast<unsigned>(wp)));
+            // (byte address: the rank among the survivors, scaled, on the scalar side's wrapped write position)
+            constexpr int ES = WIDE ? 3 : 2;
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
+            const unsigned at = ((rank << ES) + ((static_cast<unsigned>(wp) & (P3M_POOL_CAP - 1)) << ES)) & ((P3M_POOL_CAP - 1) << ES);
             Entry entry;
             if constexpr (WIDE) entry = make_uint2(static_cast<unsigned>(lane), static_cast<unsigned>(j + u));
             else entry = entry0 + static_cast<unsigned>(u);
-            if (in_run & near) ring[at & (P3M_POOL_CAP - 1)] = entry;
+            if (in_run & near) *reinterpret_cast<Entry*>(reinterpret_cast<char*>(ring) + at) = entry;
             wp += __popcll(m);
             if (u % 4 == 3)       // at most 127 left + 4 * 64 new entries in a ring of 512
                 while (wp - rp >= 128) drain(std::integral_constant<int, 2>{}, std::true_type{}, 128);
