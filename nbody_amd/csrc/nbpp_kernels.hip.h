@@ -1575,7 +1575,9 @@ __global__ void __launch_bounds__(PWG) k_p3m_pool(const P3MArgs a) {
 constexpr int P3M_ROWS_ABREAST = 2;   // rows of a target walked side by side (1, 2, 4: 0.061 / 0.058 / 0.058 ms on a
                                       // near-uniform 32^3 set, 0.089 / 0.091 / 0.099 ms on a clustered one)
 constexpr int P3M_ROWS_LANES = 8;     // lanes per target when the kernel is chosen by itself
-constexpr double P3M_ROWS_LARGE_MIN_OCCUPANCY = 64.0;   // clustering measure from which it also takes sets that fill the GPU
+constexpr double P3M_ROWS_LARGE_MIN_OCCUPANCY = 1024.0; // clustering measure from which it also takes sets that fill the GPU: beyond
+                                                        // anything measured (128^3 in blobs, measure 95 / 186 / 298 / 442: 6.97 / 11.4 /
+                                                        // 8.07 / 11.3 ms against 6.19 / 11.0 / 7.61 / 10.9 with k_p3m_rows_pool)
 constexpr double P3M_ROWS_POOL_MIN_OCCUPANCY = 2.7;     // ... and from which k_p3m_rows_pool takes them below that
 constexpr int P3M_ROWS_LARGE_LANES = 4;                 // with one lane per target, and its lanes per target there
 

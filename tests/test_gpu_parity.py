@@ -1067,11 +1067,11 @@ def test_small_sets_get_the_row_walking_kernel_by_themselves(lib, oracle):
     assert normalised_error(kinds["auto"][0], kinds["never"][0], floor) < 1e-12
 
 
-def test_heavily_clustered_large_set_gets_the_row_walking_kernel(lib, oracle):
+def test_heavily_clustered_large_set_with_the_row_walking_kernels(lib, oracle):
     """128^3 particles in 400 tight blobs (clustering measure in the hundreds): enough targets for
-    one lane each, yet k_p3m_rows (4 lanes per target) is chosen by itself.  The same exact
-    accepted-pair count as the pooled kernel, sums equal to it to rounding, and sampled targets
-    against the oracle."""
+    one lane each.  The library's own choice is the row walk with the pooled drain; k_p3m_rows with
+    4 lanes per target, asked for, takes the set as well.  The same exact accepted-pair count as
+    the pooled kernel, sums equal to it to rounding, and sampled targets against the oracle."""
     import torch
     n_side = 128
     n = n_side ** 3
@@ -1082,8 +1082,10 @@ def test_heavily_clustered_large_set_gets_the_row_walking_kernel(lib, oracle):
     dev = _t(pos + [m])
     out = {}
     try:
-        for label, lanes in (("auto", 0), ("pooled", 1)):
+        for label, lanes, rows, rows_pooled in (("auto", 0, 0, 0), ("rows", 0, 4, -1), ("pooled", 1, 0, 0)):
             lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, lanes)
+            lib.set_option(ffi.OPT_P3M_ROW_LANES, rows)
+            lib.set_option(ffi.OPT_P3M_ROWS_POOLED, rows_pooled)
             acc = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
             lib.accumulate_device(p, *dev, *acc)
             torch.cuda.synchronize()
@@ -1091,15 +1093,20 @@ def test_heavily_clustered_large_set_gets_the_row_walking_kernel(lib, oracle):
             out[label] = ([a.cpu().numpy() for a in acc], st["p3m_pooled"], st["pairs_accepted"], st["cell_occupancy"])
     finally:
         lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
-    assert out["auto"][1] == 3 and out["pooled"][1] == 1 and out["auto"][3] > 100.0
+        lib.set_option(ffi.OPT_P3M_ROW_LANES, 0)
+        lib.set_option(ffi.OPT_P3M_ROWS_POOLED, 0)
+    assert out["auto"][1] == 4 and out["rows"][1] == 3 and out["pooled"][1] == 1 and out["auto"][3] > 100.0
+    assert out["rows"][2] == out["pooled"][2]
     assert out["auto"][2] == out["pooled"][2] > 1000 * n
     floor = pair_force_scale(p, m, n) * 1e-3
     assert normalised_error(out["auto"][0], out["pooled"][0], floor) < 1e-11
+    assert normalised_error(out["rows"][0], out["pooled"][0], floor) < 1e-11
     rng = np.random.default_rng(2)
     for begin in rng.choice(n - 8, 4, replace=False):
         begin = int(begin)
         want = oracle.accumulate(p, *pos, m, tgt_begin=begin, n_tgt=8, traversal=O.EXACT_CELLS)
-        assert normalised_error([g[begin:begin + 8] for g in out["auto"][0]], want, floor) < TOL
+        for label in ("auto", "rows"):
+            assert normalised_error([g[begin:begin + 8] for g in out[label][0]], want, floor) < TOL
 
 
 @pytest.mark.parametrize("threads", [64, 128, 256])
