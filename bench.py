@@ -19,10 +19,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 128 flop/clk x 2.4 GHz
 FLOPS_PER_PAIR_DIRECT = 25       # periodic, softened direct PP (FMA = 2, rsqrt = 1)
 FLOPS_PER_PAIR_P3M = 40          # per accepted P3M pair
+# what nbpp_stats.p3m_pooled says of the most recent P3M call
+P3M_KERNEL_NAMES = {0: "k_p3m_cells (every ordered pair, one lane per target)",
+                    1: "k_p3m_pool (survivors pooled per wavefront)",
+                    2: "k_p3m_sym (every unordered pair once, reactions gathered per brick in LDS)",
+                    3: "k_p3m_rows (the lanes of a target walk its rows together)",
+                    4: "k_p3m_rows_pool (row walk, survivors pooled per wavefront)"}
 
 
 def cpu_baseline(p, pos, m, mode, budget_s=15.0):
@@ -128,11 +135,7 @@ def extra_p3m256(lib, ffi, torch, dev, stream, steps=6, warmup=2):
             "value": accepted * steps / elapsed / 1e9, "unit": "G accepted pairs/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
             "pairs_accepted": accepted,
-            "kernel": {0: "k_p3m_cells (every ordered pair, one lane per target)",
-                       1: "k_p3m_pool (survivors pooled per wavefront)",
-                       2: "k_p3m_sym (every unordered pair once, reactions gathered per brick in LDS)",
-                       3: "k_p3m_rows (the lanes of a target walk its rows together)",
-                       4: "k_p3m_rows_pool (row walk, survivors pooled per wavefront)"}[st["p3m_pooled"]],
+            "kernel": P3M_KERNEL_NAMES[st["p3m_pooled"]],
             "kernel_ms": k_ms,
             "prepare_ms": float(np.mean(prep_ms)),
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
@@ -224,6 +227,99 @@ def extra_step128(cycles=100):
     return out
 
 
+def extra_p3m128_evolved(lib, ffi, torch, dev, stream, cycles=12000, steps=8, warmup=2):
+    """The short-range force on a CLUSTERED state, under the same clock: the product's C++ engine (a
+    child process) evolves tools/configs/p3m_hydro_128.ini for `cycles` KDK cycles (12 000: a = 0.51)
+    and writes its particles; the short-range call alone is then timed here on that state, with the
+    kernel the library picks.  Runs spend most of their cycles clustered; the jittered lattice of
+    `p3m256` is the even case."""
+    import subprocess
+    import tempfile
+    from nbody_amd import Config
+    exe = os.path.join(ROOT, "nbody_amd", "host", "nbody_host_tests")
+    ini = os.path.join(ROOT, "tools", "configs", "p3m_hydro_128.ini")
+    if not os.path.exists(exe):
+        return {"error": f"{exe} not built"}
+    with tempfile.TemporaryDirectory() as tmp:
+        text = open(ini).read().replace("debug_info_every_cycles = 2000", "debug_info_every_cycles = 0")
+        text += "save_hdf5_every_delta_a = 10\n"          # two snapshots: the start and the last cycle
+        evolve_ini = os.path.join(tmp, "evolve.ini")
+        open(evolve_ini, "w").write(text)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "run", evolve_ini, str(cycles), os.path.join(tmp, "state")],
+                           capture_output=True, text=True, timeout=400)
+        evolve_s = time.perf_counter() - t0
+        last = os.path.join(tmp, "state_0001.bin")
+        if r.returncode != 0 or not os.path.exists(last):
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        raw = np.fromfile(last, dtype=np.float64)
+    n, n_side, a_now = int(raw[0]), int(raw[1]), float(raw[2])
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    p = config.pp_params()
+    x, y, z = [torch.from_numpy(np.ascontiguousarray(raw[6 + c * n: 6 + (c + 1) * n])).to(dev) for c in range(3)]
+    mass = torch.from_numpy(np.ascontiguousarray(raw[6 + 3 * n: 6 + 4 * n])).to(dev)
+    acc = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(3)]
+    for k in (ffi.OPT_TARGETS_PER_LANE, ffi.OPT_FORCE_KERNEL, ffi.OPT_P3M_SEARCH_RADIUS,
+              ffi.OPT_P3M_LANES_PER_TARGET, ffi.OPT_DETERMINISTIC):
+        lib.set_option(k, 0)
+    for _ in range(warmup):
+        lib.accumulate_device(p, x, y, z, mass, *acc, stream=stream)
+    torch.cuda.synchronize()
+    kernel_ms, prep_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lib.accumulate_device(p, x, y, z, mass, *acc, stream=stream)
+        st = lib.stats()
+        kernel_ms.append(st["pair_kernel_ms"])
+        prep_ms.append(st["prepare_ms"])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    accepted = float(st["pairs_accepted"])
+    k_ms = float(np.mean(kernel_ms))
+    achieved = accepted * FLOPS_PER_PAIR_P3M / (k_ms * 1e-3) / 1e12
+    return {"workload": f"P3M short range on the state the engine reaches after {cycles} cycles of "
+                        f"tools/configs/p3m_hydro_128.ini (128^3 particles, a = {a_now:.3f})",
+            "scale_factor": a_now, "evolve_seconds": evolve_s, "cell_occupancy_measure": st["cell_occupancy"],
+            "value": accepted * steps / elapsed / 1e9, "unit": "G accepted pairs/s",
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+            "pairs_accepted": accepted, "kernel": P3M_KERNEL_NAMES[st["p3m_pooled"]],
+            "kernel_ms": k_ms, "prepare_ms": float(np.mean(prep_ms)),
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                         "flops_per_accepted_pair": FLOPS_PER_PAIR_P3M}}
+
+
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as children (one process per
+    GPU through torch.distributed.run), pass rank 0's JSON line on and exit with the children's
+    worst return code.  This parent never initialises the GPU (no torch, no HIP): a process that
+    has may not be replaced, and it has nothing to compute."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:                       # launcher chatter: keep stdout to the one JSON line
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks printed {lines} result lines, expected one", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     if os.environ.get("NBODY_BENCH_WATCHDOG"):   # seconds: dump every thread's stack and exit if still running
         import faulthandler
@@ -237,8 +333,8 @@ def main():
     ap.add_argument("--mode", choices=["direct", "p3m"], default="direct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the P3M 256^3 and 128^3 whole-step figures that ride along in the "
-                         "default one-GPU line (`extra`)")
+                    help="skip the P3M 256^3, evolved 128^3 and whole-step figures that ride along in "
+                         "the default one-GPU line (`extra`)")
     ap.add_argument("--per-lane", type=int, default=0)
     ap.add_argument("--force-kernel", type=int, default=0)
     ap.add_argument("--p3m-radius", type=int, default=0)
@@ -250,19 +346,18 @@ def main():
     ap.add_argument("--with-mesh", action="store_true",
                     help="p3m mode, one GPU: a step is the whole force phase, mesh force "
                          "(libnbpm) then short range accumulated onto it")
-    ap.add_argument("--comm", choices=["native", "torch"], default="native",
-                    help="several GPUs: 'native' = libnbmg (the library owns the RCCL communicator, "
-                         "ncclAllGather / ncclReduceScatter below the C ABI), 'torch' = the same "
-                         "collectives issued through torch.distributed")
-    ap.add_argument("--halo-exchange", action="store_true",
-                    help="P3M on several GPUs, native path: send each peer only the particles within a "
-                         "cutoff radius of its block instead of all-gathering every position")
+    ap.add_argument("--halo-exchange", type=int, default=0,
+                    help="P3M on several GPUs: 1 = send each peer only the particles within a cutoff "
+                         "radius of its block, -1 = all-gather every position (0 = the library's default)")
     ap.add_argument("--native-one-rank", action="store_true",
                     help="one GPU: go through libnbmg with a communicator of one rank (exercises the "
                          "multi-GPU code path on a single-GPU box)")
     ap.add_argument("--ordered", action="store_true",
                     help="bitwise-reproducible ordered-pair kernel (NBPP_OPT_DETERMINISTIC)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -274,13 +369,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Rehearsal of the multi-rank flow on a box with ONE GPU (never what the scaling numbers come
-    # from): NBODY_BENCH_ONE_DEVICE=1 puts every rank on device 0 and uses gloo, since RCCL does
-    # not accept two ranks on one device.
-    rehearsal = os.environ.get("NBODY_BENCH_ONE_DEVICE") == "1"
+    # from): NBODY_BENCH_ONE_DEVICE=1 puts every rank on device 0.  RCCL does not accept two ranks on
+    # one device, so libnbmg is asked for its host-staged transport (NBMG_TRANSPORT=host: the same
+    # library calls, the collectives carried through shared host memory) and torch.distributed uses gloo.
+    rehearsal = world > 1 and os.environ.get("NBODY_BENCH_ONE_DEVICE") == "1"
     if rehearsal:
         local_rank = 0
+        os.environ["NBMG_TRANSPORT"] = "host"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -306,72 +403,51 @@ def main():
     p = config.pp_params()
     pos = datasets.jittered_lattice(n_side)           # same seeded set on every rank
     m = np.full(n, config.DM_PARTICLE_MASS)
-
-    # i-partition (nbody_amd/distributed.py): each rank owns a contiguous slice of x, y, z,
-    # resident on its GPU; masses are all-gathered once, positions every step
-    from nbody_amd.distributed import SlicedParticles, force_evaluation
-    parts = SlicedParticles(n, rank, world, dev)
-    parts.set_own_from_global(*[torch.from_numpy(c).to(dev) for c in pos])
-    begin, mine, counts = parts.begin, parts.count, parts.counts
-    mass = parts.gather_scalar_field(torch.from_numpy(m[begin:begin + mine]).to(dev)).contiguous()
-    acc = [torch.zeros(mine, dtype=torch.float64, device=dev) for _ in range(3)]
     stream = torch.cuda.current_stream().cuda_stream
 
-    def compute(x, y, z, mm, ax, ay, az, tgt_begin, n_tgt):
-        lib.accumulate_device(p, x, y, z, mm, ax, ay, az, tgt_begin=tgt_begin, n_tgt=n_tgt,
-                              stream=stream)
-
-    def compute_pairs(x, y, z, mm, fx, fy, fz, part, n_parts):
-        lib.accumulate_pairs_device(p, x, y, z, mm, fx, fy, fz, part=part, n_parts=n_parts,
-                                    stream=stream)
-
-    # several GPUs, native path: libnbmg owns an RCCL communicator of its own; torch.distributed
-    # only carries the communicator id to the ranks and the barrier / max-over-ranks of the timing
+    # Two ways through a step, never mixed and never chosen behind the caller's back:
+    #   one GPU       -> nbpp_accumulate_device on the whole set (comm_backend "none");
+    #   several ranks -> libnbmg only: its own communicator below the C ABI; torch.distributed carries
+    #                    the 128-byte communicator id and the timing barrier.  If the library cannot
+    #                    start, the run fails (non-zero exit): there is nothing to fall back to.
     mg = None
-    comm_note = None
     if world == 1 and args.native_one_rank:
         mg = nbody_amd.load_multi_gpu()
         mg.init(0, 1, None, local_rank)
-        mg.set_option(ffi.MG_OPT_TIMING, 1)
         mg.set_option(ffi.MG_OPT_PAIR_SHARES, -1 if args.ordered else 1)
-    if world > 1 and args.comm == "native" and not rehearsal:
-        try:
-            mg = nbody_amd.load_multi_gpu()
-            ident = torch.zeros(ffi.MG_UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                ident.copy_(torch.frombuffer(bytearray(mg.unique_id()), dtype=torch.uint8))
-            dist.broadcast(ident, src=0)
-            mg.init(rank, world, bytes(ident.cpu().numpy().tobytes()), local_rank)
-            mg.set_option(ffi.MG_OPT_TIMING, 1)
-            mg.set_option(ffi.MG_OPT_PAIR_SHARES, -1 if args.ordered else 0)
-            mg.set_option(ffi.MG_OPT_HALO_EXCHANGE, 1 if args.halo_exchange else 0)
-            ok = 1
-        except Exception as e:   # every rank must take the same path: agree below
-            comm_note = f"native multi-GPU layer failed to start ({e!r}); torch.distributed collectives used"
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            mg = None
-            comm_note = comm_note or "native multi-GPU layer failed on another rank; torch.distributed collectives used"
+    elif world > 1:
+        mg = nbody_amd.load_multi_gpu()
+        ident = torch.zeros(ffi.MG_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cpu" if rehearsal else dev)
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(mg.unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, src=0)
+        mg.init(rank, world, bytes(ident.cpu().numpy().tobytes()), local_rank)
+        mg.set_option(ffi.MG_OPT_PAIR_SHARES, -1 if args.ordered else 0)
     if mg is not None:
+        mg.set_option(ffi.MG_OPT_TIMING, 1)
+        if args.halo_exchange:
+            mg.set_option(ffi.MG_OPT_HALO_EXCHANGE, args.halo_exchange)
+        comm_backend = {"rccl": "RCCL via libnbmg (C ABI)",
+                        "host": "libnbmg (C ABI) over its host-staged transport - REHEARSAL: every rank "
+                                "on one GPU; not a scaling measurement"}[mg.transport()]
+        if (mg.transport() == "host") != rehearsal:
+            raise SystemExit(f"libnbmg runs on its {mg.transport()} transport, rehearsal={rehearsal}")
         nb_begin, nb_count = mg.partition(n, rank, world)
         nb_own = [torch.from_numpy(c[nb_begin:nb_begin + nb_count].copy()).to(dev) for c in pos]
         nb_mass = torch.zeros(mg.padded_length(n, world), dtype=torch.float64, device=dev)
         nb_mass[:n] = config.DM_PARTICLE_MASS
         nb_acc = [torch.zeros(max(nb_count, 1), dtype=torch.float64, device=dev) for _ in range(3)]
+        first_count = mg.partition(n, 0, world)[1]
+    else:
+        comm_backend = "none (one GPU)"
+        x, y, z = [torch.from_numpy(c).to(dev) for c in pos]
+        mass = torch.from_numpy(m).to(dev)
+        acc = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(3)]
+        first_count = n
     comm_ms = []
-
-    from nbody_amd.distributed import force_evaluation_pairs
-    # direct summation on several GPUs: every unordered pair once, shared out over the ranks,
-    # accelerations combined by reduce-scatter; one GPU (or P3M): the ordinary entry point,
-    # which picks the same pair-once kernel by itself for a full direct evaluation
-    use_pairs = world > 1 and not use_pm and not args.ordered
-    work = [None]
-
     mesh = None
     if args.with_mesh:
-        if not use_pm or world != 1:
+        if not use_pm or world != 1 or mg is not None:
             raise SystemExit("--with-mesh needs --mode p3m on one GPU")
         mesh = nbody_amd.load_mesh(device=local_rank)
         mesh.set_timing(True)
@@ -380,8 +456,8 @@ def main():
 
     def step():
         if mg is not None:
-            # the multi-GPU compute_pp_forces of libnbmg: all-gather of positions, this rank's share
-            # of the pairs, reduce-scatter (direct) or this rank's targets (P3M / --ordered)
+            # the multi-GPU compute_pp_forces of libnbmg: all-gather of positions (or halo trade), this
+            # rank's share of the pairs + reduce-scatter (direct) or this rank's targets (P3M / --ordered)
             for a in nb_acc:
                 a.zero_()
             mg.accumulate_device(p, n, *nb_own, nb_mass, *nb_acc, stream=stream)
@@ -389,15 +465,12 @@ def main():
             comm_ms.append((ms["allgather_ms"], ms["reduce_ms"], ms["compute_ms"]))
             return lib.stats()
         if mesh is not None:   # src/integrator.cpp:239-258: the mesh force overwrites, PP adds
-            x, y, z = parts.gather_positions()
             mesh.accelerations_device(mesh_params, x, y, z, mass, *acc, stream=stream)
             mesh_ms.append(mesh.stats()["total_ms"])
-            lib.accumulate_device(p, x, y, z, mass, *acc, stream=stream)
-            return lib.stats()
-        if use_pairs:
-            work[0] = force_evaluation_pairs(parts, mass, acc, compute_pairs, work[0])
-        else:
-            force_evaluation(parts, mass, acc, compute)
+        else:                  # PP only: the caller zero-fills first (src/integrator.cpp:246-251)
+            for a in acc:
+                a.zero_()
+        lib.accumulate_device(p, x, y, z, mass, *acc, stream=stream)
         return lib.stats()
 
     def fence():
@@ -421,7 +494,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(accepted)], dtype=torch.float64,
-                     device=dev)
+                     device="cpu" if rehearsal else dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -445,10 +518,10 @@ def main():
             workload = f"PP direct summation fp64, N={n_side}^3, periodic box"
         value = pairs_per_step * args.steps / elapsed / 1e9
         # dominant kernel on rank 0's share: algorithmic flops of one launch / its duration
-        pair_shares = use_pairs if mg is None else bool(mg.stats()["pair_shares"])
-        my_pairs = pairs_per_step / world if pair_shares else pairs_per_step * (counts[0] / n)
+        pair_shares = mg is not None and bool(mg.stats()["pair_shares"])
+        my_pairs = pairs_per_step / world if pair_shares else pairs_per_step * (first_count / n)
         kernel_names = {1: "k_pairs (ordered pairs)", 2: "k_pairs (per-pair wrap)",
-                        3: ["k_p3m_cells", "k_p3m_pool", "k_p3m_sym", "k_p3m_rows", "k_p3m_rows_pool"][st.get("p3m_pooled", 0)],
+                        3: P3M_KERNEL_NAMES[st.get("p3m_pooled", 0)].split(" ")[0],
                         4: "k_pairs (P3M, all pairs)",
                         5: "k_pairs_sym (each unordered pair once, both directions)"}
         achieved = my_pairs * flops / (kernel_avg_ms * 1e-3) / 1e12
@@ -456,21 +529,28 @@ def main():
         # ordered kernel 25 (no per-pair wrap, +6 for the rsqrt refinement); the pair-once
         # kernel issues 31 per unordered pair
         executed = {1: 25.0, 2: 31.0, 5: 15.5}.get(st.get("kernel_variant"))
-        # HBM bytes per launch come from the committed rocprofv3 counter passes of this same
-        # command (FETCH_SIZE doubled as the gfx950 correction requires, plus WRITE_SIZE)
+        # HBM bytes per launch and the FP64 pipe occupancy come from the committed rocprofv3 counter
+        # passes of this same command (FETCH_SIZE doubled as the gfx950 correction requires, plus
+        # WRITE_SIZE) - quoted only while the profile was taken from the kernel sources of this tree
         traffic = pipe_busy = None
+        stale = None
         prof = os.path.join(ROOT, "profiles", "latest_direct128.json" if not use_pm else "latest_p3m.json")
         if os.path.exists(prof) and world == 1 and n_side == (128 if not use_pm else 256):
-            d = json.load(open(prof)).get("derived", {})
-            if "hbm_fetch_bytes_x2" in d and "hbm_write_bytes" in d:
-                traffic = d["hbm_fetch_bytes_x2"] + d["hbm_write_bytes"]
-            pipe_busy = d.get("fp64_pipe_busy_frac")
+            from source_sha import kernel_sources_sha
+            pj = json.load(open(prof))
+            stale = pj.get("kernel_sources_sha") != kernel_sources_sha()
+            if not stale:
+                d = pj.get("derived", {})
+                if "hbm_fetch_bytes_x2" in d and "hbm_write_bytes" in d:
+                    traffic = d["hbm_fetch_bytes_x2"] + d["hbm_write_bytes"]
+                pipe_busy = d.get("fp64_pipe_busy_frac")
         line = {
             "metric": "pair interactions/sec", "value": value, "unit": "Ginter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic" + (" (REHEARSAL: all ranks share one GPU, gloo)" if rehearsal else ""),
+            "data": "synthetic" + (" (REHEARSAL: all ranks share one GPU)" if rehearsal else ""),
+            "comm_backend": comm_backend,
             "config": {"workload": workload, "n_particles": n, "parallelism": f"i-partition x{world}",
                        "flops_per_interaction": flops,
                        "kernel": kernel_names.get(st.get("kernel_variant"), "?"),
@@ -489,54 +569,47 @@ def main():
                                       "kernel serves two interactions with one evaluation); fp64_pipe_busy_frac is "
                                       "the FP64 pipe occupancy from the committed rocprofv3 counter pass",
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, committed profile of this command)",
+                         "stale_profile": stale,
                          "algorithmic_bytes": 56.0 * n, "kernel_ms": kernel_avg_ms,
                          "prepare_ms": float(np.mean(prep_ms)),
                          "subtiles_wrapped_frac": (st.get("subtiles_wrapped", 0) /
                                                    max(1, st.get("subtiles_total", 0)))},
         }
-        if world > 1 or mg is not None:
-            if mg is not None:
-                ag, rs, cp = (float(np.mean([c[k] for c in comm_ms])) for k in range(3))
-                st_mg = mg.stats()
-                halo = args.mode == "p3m" and args.halo_exchange and world > 1
-                line["config"]["parallelism"] = (
-                    f"block partition x{world}, libnbmg: "
-                    + ("halo exchange (ncclSend / ncclRecv of the particles within a cutoff radius of a "
-                       "peer's block), " if halo else "ncclAllGather of positions per evaluation, ")
-                    + ("shares of the unordered pairs + ncclReduceScatter" if pair_shares
-                       else "own targets against all sources, no reduction"))
-                line["comm"] = {"backend": "RCCL via libnbmg (C ABI)", "allgather_ms": ag, "reduce_scatter_ms": rs,
-                                "compute_ms": cp, "allgather_bytes_per_rank": st_mg["allgather_bytes"],
-                                "reduce_bytes_per_rank": st_mg["reduce_bytes"],
-                                "halo_particles_rank0": st_mg["halo_particles"], "rank": 0}
-            else:
-                line["comm"] = {"backend": "gloo (rehearsal)" if rehearsal else "RCCL via torch.distributed",
-                                "note": comm_note}
+        if mg is not None:
+            ag, rs, cp = (float(np.mean([c[k] for c in comm_ms])) for k in range(3))
+            st_mg = mg.stats()
+            halo = bool(st_mg["halo_exchange"])
+            line["config"]["parallelism"] = (
+                f"block partition x{world}, libnbmg: "
+                + ("halo exchange (ncclSend / ncclRecv of the particles within a cutoff radius of a "
+                   "peer's block), " if halo else "ncclAllGather of positions per evaluation, ")
+                + ("shares of the unordered pairs + ncclReduceScatter" if pair_shares
+                   else "own targets against all sources, no reduction"))
+            line["comm"] = {"backend": comm_backend, "allgather_ms": ag, "reduce_scatter_ms": rs,
+                            "compute_ms": cp, "allgather_bytes_per_rank": st_mg["allgather_bytes"],
+                            "reduce_bytes_per_rank": st_mg["reduce_bytes"],
+                            "halo_particles_rank0": st_mg["halo_particles"], "rank": 0}
         if mesh is not None:
             line["config"]["mesh_force_ms"] = float(np.mean(mesh_ms[args.warmup:]))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(p, pos, m, args.mode)
-        default_run = (world == 1 and args.mode == "direct" and n_side == 128 and not args.with_mesh
-                       and not args.no_extras)
+        default_run = (world == 1 and mg is None and args.mode == "direct" and n_side == 128
+                       and not args.with_mesh and not args.no_extras)
         if default_run:
             # the other single-GPU configurations of the baseline, measured by the same process
             # under the same clock (not part of `value`)
-            del parts, acc, mass
+            del x, y, z, acc, mass
             torch.cuda.empty_cache()
             extra = {}
-            try:
-                extra["p3m256"] = extra_p3m256(lib, ffi, torch, dev, stream)
-            except Exception as e:   # the headline line must still be printed
-                extra["p3m256"] = {"error": repr(e)}
-            torch.cuda.empty_cache()
-            try:
-                extra["kdk32"] = extra_kdk32(lib, ffi, torch, dev, stream)
-            except Exception as e:
-                extra["kdk32"] = {"error": repr(e)}
-            try:
-                extra["step128"] = extra_step128()
-            except Exception as e:
-                extra["step128"] = {"error": repr(e)}
+            for name, fn in (("p3m256", lambda: extra_p3m256(lib, ffi, torch, dev, stream)),
+                             ("kdk32", lambda: extra_kdk32(lib, ffi, torch, dev, stream)),
+                             ("step128", extra_step128),
+                             ("p3m128_evolved", lambda: extra_p3m128_evolved(lib, ffi, torch, dev, stream))):
+                try:
+                    extra[name] = fn()
+                except Exception as e:   # the headline line must still be printed
+                    extra[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
             line["extra"] = extra
         print(json.dumps(line), flush=True)
     if world > 1:

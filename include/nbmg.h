@@ -36,7 +36,8 @@ typedef enum nbmg_status {
     NBMG_ERR_HIP = -2,
     NBMG_ERR_NOINIT = -3,
     NBMG_ERR_NBPP = -4,        /* a libnbpp call failed (message carries nbpp_last_error())   */
-    NBMG_ERR_RCCL = -5,        /* an RCCL call failed (message carries ncclGetErrorString())  */
+    NBMG_ERR_RCCL = -5,        /* a collective failed: RCCL's message, or on the host transport
+                                  "ranks disagree on the collective" / a peer that never came */
     NBMG_ERR_RENDEZVOUS = -6   /* the ranks could not exchange the communicator id            */
 } nbmg_status;
 
@@ -52,7 +53,7 @@ typedef struct nbmg_stats {
     uint64_t reduce_bytes;    /* bytes this rank sent into the reduce-scatters                */
     int32_t pair_shares;      /* 1: every unordered pair once across the ranks + reduce-scatter;
                                  0: this rank's targets against all sources, no reduction     */
-    int32_t reserved;
+    int32_t halo_exchange;    /* 1: the call traded halos instead of all-gathering positions  */
     uint64_t halo_particles;  /* halo exchange: particles this rank received from its peers
                                  (allgather_bytes then counts their 32 bytes each)           */
 } nbmg_stats;
@@ -63,24 +64,40 @@ enum {
                                  more than one rank), 1 = always, -1 = never (i-partition,
                                  all-gather only, bitwise reproducible with
                                  NBPP_OPT_DETERMINISTIC)                                        */
-    NBMG_OPT_HALO_EXCHANGE = 3 /* P3M short range on more than one rank: 1 = instead of
-                                 all-gathering every position, each rank sends a peer only its
-                                 particles within a cutoff radius of that peer's block
+    NBMG_OPT_HALO_EXCHANGE = 3 /* P3M short range on more than one rank: instead of all-gathering
+                                 every position, each rank sends a peer only its particles
+                                 within a cutoff radius of that peer's block
                                  (nbmg_x_extent_device, nbmg_halo_select_device, ncclSend /
-                                 ncclRecv); 0 = all-gather (default); 2 = that code path on
-                                 one rank too (nothing travels; for tests)                      */
+                                 ncclRecv).  0 = automatic (default): halos whenever every
+                                 block is a slab in x (its interval, widened by the cutoff
+                                 radius on both sides, shorter than half the box - every rank
+                                 sees the same intervals and decides alike), else the
+                                 all-gather; 1 = always; -1 = never; 2 = that code path on one
+                                 rank too (nothing travels; for tests)                          */
 };
 
 /*
  * Lifecycle.  Rank 0 obtains a communicator id (nbmg_get_unique_id) and hands its
  * NBMG_UNIQUE_ID_BYTES bytes to the other ranks by any means the launcher has; every rank then
  * calls nbmg_init(rank, nranks, id, device), which binds the process to HIP device `device`
- * (nbpp_init) and creates the RCCL communicator.  nranks == 1 needs no id (id may be NULL).
+ * (nbpp_init) and creates the RCCL communicator; a failed nbmg_init leaves nothing allocated.
+ * nranks == 1 needs no id (id may be NULL).
  * nbmg_init_from_env does both for processes started by a launcher that sets RANK, WORLD_SIZE
  * and LOCAL_RANK (torch.distributed.run, mpirun wrappers): rank 0 writes the id to the file named
- * by NBMG_ID_FILE (default /tmp/nbmg_id_<MASTER_PORT>), the others wait for it; without
- * WORLD_SIZE it is nbmg_init(0, 1, NULL, 0).  NBMG_HALO_EXCHANGE in the environment sets the option
- * of that name.
+ * by NBMG_ID_FILE (default: /tmp/nbmg-<uid>/id_<MASTER_PORT>_<launcher pid or NBMG_RUN_TOKEN>, in a
+ * directory only this user can write; an older file of that name is removed first), the others wait
+ * for it; without WORLD_SIZE it is nbmg_init(0, 1, NULL, 0).  NBMG_HALO_EXCHANGE in the environment
+ * sets the option of that name.
+ *
+ * Transport.  RCCL, one GPU per rank, is the product.  With NBMG_TRANSPORT=host in rank 0's
+ * environment when it draws the id, the id names a POSIX shared-memory segment instead and every
+ * rank that is given it carries the same collectives through host memory (device -> segment ->
+ * device, a barrier in between).  That is for ranks that SHARE a GPU, which RCCL refuses: a
+ * rehearsal of the multi-rank flow on a one-GPU machine, never a measurement.  Its barrier also
+ * checks that all ranks are in the same collective and gives NBMG_ERR_RCCL instead of a hang when
+ * they are not, or when a peer does not arrive within NBMG_HOST_TRANSPORT_TIMEOUT (120) seconds.
+ * NBMG_ONE_DEVICE=<d> makes nbmg_init_from_env put every rank on device d.  nbmg_transport()
+ * names the transport in use ("rccl", "host", "" before nbmg_init).
  * Replaces: the implicit single device of the reference's `omp target` region
  * (src/particles.cpp:169).
  */
@@ -91,6 +108,7 @@ void nbmg_shutdown(void);
 const char* nbmg_last_error(void);
 int nbmg_rank(void);     /* -1 before nbmg_init */
 int nbmg_nranks(void);   /*  0 before nbmg_init */
+const char* nbmg_transport(void);
 int nbmg_set_option(int key, int64_t value);
 int nbmg_get_stats(nbmg_stats* out);
 

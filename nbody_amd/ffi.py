@@ -525,7 +525,7 @@ MG_EXPORTS = (
     "nbmg_rank", "nbmg_nranks", "nbmg_set_option", "nbmg_get_stats", "nbmg_partition",
     "nbmg_padded_length", "nbmg_allgather_device", "nbmg_allreduce_sum_device",
     "nbmg_allreduce_max_device", "nbmg_accumulate_device", "nbmg_max_accel_sq_device",
-    "nbmg_x_extent_device", "nbmg_halo_select_device",
+    "nbmg_x_extent_device", "nbmg_halo_select_device", "nbmg_transport",
 )
 MG_UNIQUE_ID_BYTES = 128
 MG_OPT_TIMING, MG_OPT_PAIR_SHARES, MG_OPT_HALO_EXCHANGE = 1, 2, 3
@@ -534,7 +534,7 @@ MG_OPT_TIMING, MG_OPT_PAIR_SHARES, MG_OPT_HALO_EXCHANGE = 1, 2, 3
 class MultiGpuStats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("allgather_ms", "compute_ms", "reduce_ms", "total_ms")] + [
         ("allgather_bytes", C.c_uint64), ("reduce_bytes", C.c_uint64),
-        ("pair_shares", C.c_int32), ("reserved", C.c_int32), ("halo_particles", C.c_uint64)]
+        ("pair_shares", C.c_int32), ("halo_exchange", C.c_int32), ("halo_particles", C.c_uint64)]
 
 
 class MultiGpuLibrary:
@@ -557,6 +557,7 @@ class MultiGpuLibrary:
         L.nbmg_init.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.nbmg_shutdown.restype = None
         L.nbmg_last_error.restype = C.c_char_p
+        L.nbmg_transport.restype = C.c_char_p
         L.nbmg_set_option.argtypes = [C.c_int, C.c_int64]
         L.nbmg_get_stats.argtypes = [C.POINTER(MultiGpuStats)]
         L.nbmg_partition.argtypes = [C.c_size_t, C.c_int, C.c_int, SZ, SZ]
@@ -598,7 +599,11 @@ class MultiGpuLibrary:
     def stats(self):
         s = MultiGpuStats()
         self._check(self.lib.nbmg_get_stats(C.byref(s)))
-        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def transport(self) -> str:
+        """"rccl", "host" (collectives staged through shared host memory: ranks sharing one GPU), or ""."""
+        return self.lib.nbmg_transport().decode()
 
     # partition (no GPU needed) ------------------------------------------------------
     def partition(self, n, rank, nranks):

@@ -90,11 +90,16 @@ void Simulation::log_diagnostics() {
     if (options_.log_dir.empty()) return;
     DeviceEngine& engine = *engine_;
     ParticleSystem now(config_);
+    // Collective with several processes (libnbmg): download() all-gathers the particles, and
+    // download_mesh_solve() all-reduces the density when the step itself keeps no mesh (pair force
+    // only, no gas).  Every process therefore makes both calls, in this order, before the ones
+    // that do not write leave; a process that left earlier would meet the others' all-reduce with
+    // the next cycle's all-gather.
     engine.download(now);
-    if (!logger_ || !logger_->is_open()) return;
     std::vector<double> gas[9], total_rho, phi;
-    engine.download_gas(gas);
     engine.download_mesh_solve(total_rho, phi);
+    if (!logger_ || !logger_->is_open()) return;
+    engine.download_gas(gas);
     Diagnostics d = compute_diagnostics(config_, now, gas, total_rho, phi, engine.cosmo, engine.cfl_timestep(),
                                         engine.gravity_timestep(), engine.current_dt);
     d.cycle = engine.cycle_count;

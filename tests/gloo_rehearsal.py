@@ -1,9 +1,12 @@
-"""i-partition of the targets over the GPUs of one node, with an all-gather of positions per
-force evaluation (RCCL over xGMI via torch.distributed; gloo on CPU in the tests).
+"""Test helper: the i-partition of the targets over several ranks, with the collectives carried by
+torch.distributed (gloo) instead of libnbmg's RCCL communicator.  The product's multi-GPU path is
+libnbmg (include/nbmg.h); this module exists so that the partition arithmetic and the sequence of
+collectives can be rehearsed where RCCL cannot run: two gloo ranks on the CPU (tests/test_distributed.py)
+and several ranks sharing ONE GPU (bench.py with NBODY_BENCH_ONE_DEVICE=1; RCCL refuses two ranks
+on one device).
 
-The reference is single-process (one `omp target` region, src/particles.cpp:169-173); this is
-the multi-GPU counterpart of that one device boundary.  Each rank owns a contiguous slice of the
-particle index range, keeps its slice of x, y, z resident, and per evaluation
+The reference is single-process (one `omp target` region, src/particles.cpp:169-173).  Each rank owns
+a contiguous slice of the particle index range, keeps its slice of x, y, z resident, and per evaluation
 
   1. all-gathers the three coordinate arrays (masses are gathered once),
   2. computes accelerations for its own slice against all sources,

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -129,3 +130,27 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert "oracle" not in text.lower().replace("test_oracle", ""), f
+
+
+def test_bench_parent_of_a_multi_gpu_run_never_loads_the_gpu_runtime(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent only starts the ranks
+    (torch.distributed.run) and relays their line.  It must not load torch or the HIP runtime - a
+    process that has initialised the GPU has no business holding it beside its ranks.  The dynamic
+    loader itself records what each process maps (LD_DEBUG=libs, one file per pid).  Here, without a
+    GPU, the ranks fail, and the parent must pass that on as a non-zero exit code."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"LD_DEBUG": "libs", "LD_DEBUG_OUTPUT": str(tmp_path / "ld")})
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n-side", "8",
+                             "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True, env=env)
+    out, err = proc.communicate(timeout=600)
+    import torch
+    if not torch.cuda.is_available():
+        assert proc.returncode != 0 and '{"metric"' not in out
+    parent = (tmp_path / f"ld.{proc.pid}").read_text()
+    assert "libpython" in parent or "libc.so" in parent          # the record is there
+    for name in ("libamdhip64", "libtorch", "libhsa-runtime", "librccl"):
+        assert name not in parent, f"the bench parent loaded {name}"
+    others = [f for f in tmp_path.iterdir() if f.name != f"ld.{proc.pid}"]
+    assert any("libtorch" in f.read_text() for f in others)      # the ranks did start

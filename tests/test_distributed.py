@@ -1,6 +1,7 @@
 """The multi-GPU i-partition, rehearsed with two gloo ranks on CPU tensors.  The arithmetic is
 injected: here the CPU oracle stands in for the GPU kernel, so what is tested is the partition,
-the padded all-gather and the slice bookkeeping that bench.py uses unchanged on RCCL."""
+the padded all-gather and the slice bookkeeping (tests/gloo_rehearsal.py; the product's multi-GPU
+path is libnbmg, whose partition functions the second test calls directly)."""
 import os
 import socket
 import sys
@@ -30,7 +31,7 @@ def _worker(rank, world, port, n, use_pm, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import datasets
     from nbody_amd import Config
-    from nbody_amd.distributed import SlicedParticles, force_evaluation
+    from gloo_rehearsal import SlicedParticles, force_evaluation
     from oracle.oracle import Oracle
     orc = Oracle()
     pos = datasets.clustered(n)
@@ -54,7 +55,7 @@ def _worker(rank, world, port, n, use_pm, out_dir):
     if not use_pm:
         # the pair-once path: each rank fills a full-length array with its share, here "the
         # accelerations of my own slice", and the reduce-scatter must hand every rank its slice
-        from nbody_amd.distributed import force_evaluation_pairs
+        from gloo_rehearsal import force_evaluation_pairs
 
         def compute_pairs(x, y, z, mm, fx, fy, fz, part, n_parts):
             b, c = parts.begins[part], parts.counts[part]
@@ -154,7 +155,7 @@ def test_two_rank_native_block_partition(tmp_path, oracle, n):
 
 
 def test_partition_shapes():
-    from nbody_amd.distributed import partition
+    from gloo_rehearsal import partition
     for n, w in ((10, 3), (8, 8), (2097152, 8), (5, 8), (0, 2)):
         begins, counts = partition(n, w)
         assert sum(counts) == n and begins[0] == 0

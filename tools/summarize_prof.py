@@ -9,6 +9,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_sha import git_head, kernel_sources_sha  # noqa: E402
+
 
 def find(profdir, name, suffix):
     hits = glob.glob(os.path.join(profdir, name, "**", "*" + suffix), recursive=True)
@@ -18,7 +21,23 @@ def find(profdir, name, suffix):
 def main():
     profdir, out = sys.argv[1], sys.argv[2]
     pick = sys.argv[3] if len(sys.argv) > 3 else "k_pairs"
-    summary = {"kernel_filter": pick}
+    # which tree the numbers belong to: bench.py quotes a profile's counters only while the kernel
+    # sources still hash to this value (the GPU box has no .git: the head comes in as GRAFT_HEAD)
+    summary = {"kernel_filter": pick, "kernel_sources_sha": kernel_sources_sha(),
+               "git_head": os.environ.get("GRAFT_HEAD") or git_head()}
+    # the bench line the kernel-trace pass itself printed: its ms_per_step next to the traced kernel
+    # time tells how much of a difference to another box's bench line is the box (clock), and how
+    # much the tracing
+    log = os.path.join(profdir, "trace.log")
+    if os.path.exists(log):
+        for text in reversed(open(log).read().splitlines()):
+            if text.startswith('{"metric"'):
+                line = json.loads(text)
+                summary["bench_line_of_trace_pass"] = {
+                    "ms_per_step": line["ms_per_step"], "kernel_ms": line["roofline"]["kernel_ms"],
+                    "prepare_ms": line["roofline"]["prepare_ms"], "value": line["value"], "steps": line["steps"],
+                    "roofline_frac": line["roofline"]["frac"]}
+                break
     stats = find(profdir, "trace", "_kernel_stats.csv")
     rows = list(csv.DictReader(open(stats)))
     summary["kernel_stats"] = [
@@ -70,7 +89,14 @@ def main():
     summary["derived"] = d
     json.dump(summary, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as f:
-        f.write(f"# rocprofv3 summary ({os.path.basename(out)})\n\n## kernel-trace --stats\n\n")
+        f.write(f"# rocprofv3 summary ({os.path.basename(out)})\n\n")
+        f.write(f"tree: git {summary['git_head']}, kernel sources sha {summary['kernel_sources_sha']}\n\n")
+        b = summary.get("bench_line_of_trace_pass")
+        if b:
+            f.write(f"bench line of the kernel-trace pass on this box: {b['ms_per_step']:.3f} ms per step "
+                    f"({b['steps']} steps), pair kernel {b['kernel_ms']:.3f} ms + binning {b['prepare_ms']:.3f} ms by "
+                    f"the library's own HIP events, roofline.frac {b['roofline_frac']:.4f}\n\n")
+        f.write("## kernel-trace --stats\n\n")
         f.write("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n")
         for r in summary["kernel_stats"]:
             f.write(f"| `{r['name']}` | {r['calls']} | {r['avg_ms']:.4f} | {r['total_ms']:.3f} | {r['pct']:.3f} |\n")
