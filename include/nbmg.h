@@ -70,7 +70,7 @@ enum {
                                  (nbmg_x_extent_device, nbmg_halo_select_device, ncclSend /
                                  ncclRecv).  0 = automatic (default): halos whenever every
                                  block is a slab in x (its interval, widened by the cutoff
-                                 radius on both sides, shorter than half the box - every rank
+                                 radius on both sides, under 3/4 of the box - every rank      
                                  sees the same intervals and decides alike), else the
                                  all-gather; 1 = always; -1 = never; 2 = that code path on one
                                  rank too (nothing travels; for tests)                          */

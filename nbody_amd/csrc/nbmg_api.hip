@@ -806,7 +806,8 @@ namespace {
 // cutoff radius of that peer's interval, and the peers trade the packs (grouped ncclSend /
 // ncclRecv); libnbpp then works on own + received particles with the own block as targets.
 // `only_slabs`: give up (*used = false, nothing added) unless every block's interval, widened by
-// the cutoff radius on both sides, is shorter than half the box - the same decision on every
+// the cutoff radius on both sides, covers less than three quarters of the box (beyond that a rank
+// would receive most of the particles anyway) - the same decision on every
 // rank, since all of them see the same intervals.
 int accumulate_with_halos(const nbpp_params* p, size_t count, const double* own_x, const double* own_y,
                           const double* own_z, const double* own_m, double* ax, double* ay, double* az,
@@ -831,7 +832,7 @@ int accumulate_with_halos(const nbpp_params* p, size_t count, const double* own_
     auto width_of = [L](double lo, double hi) { return hi > lo ? hi - lo : hi - lo + L; };
     if (only_slabs)
         for (int r = 0; r < R; ++r)
-            if (iv[2 * r] >= 0.0 && width_of(iv[2 * r], iv[2 * r + 1]) + 2.0 * margin >= 0.5 * L) return NBMG_OK;
+            if (iv[2 * r] >= 0.0 && width_of(iv[2 * r], iv[2 * r + 1]) + 2.0 * margin >= 0.75 * L) return NBMG_OK;
     *used = true;
     // 2. what I owe every peer: count, then pack
     // (a peer whose interval, widened by the margin, does not meet mine gets nothing)
