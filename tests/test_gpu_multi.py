@@ -111,8 +111,22 @@ def test_x_extent_is_the_complement_of_the_longest_gap(mg):
     xs = 0.5 + 0.25 * rng.random(300)
     lo, hi = mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L)
     assert xs.min() - bin_w <= lo <= xs.min() and xs.max() <= hi <= xs.max() + bin_w
+    # x = L is the periodic image of x = 0: both in the first bin
     xs = np.array([0.0, L])
-    assert mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L) == (pytest.approx(L - bin_w), bin_w)
+    assert mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L) == (0.0, pytest.approx(bin_w))
+    # positions outside [0, L) are legal input (libnbpp folds them into the box): the interval is that
+    # of the folded positions, and selecting with it finds the same particles as numpy does on them
+    xs = np.concatenate([-0.3 * L + 0.05 * L * rng.random(400), 1.2 * L + 0.05 * L * rng.random(400)])
+    folded = np.mod(xs, L)                                   # [0.7 L, 0.75 L) and [0.2 L, 0.25 L)
+    lo, hi = mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L)
+    assert lo < hi and folded.min() - bin_w <= lo <= folded.min() and folded.max() <= hi <= folded.max() + bin_w
+    others = [torch.as_tensor(L * rng.random(xs.size), device="cuda:0") for _ in range(3)]
+    k = mg.halo_select_device(torch.as_tensor(xs, device="cuda:0"), *others, L, lo, hi, 0.0)
+    assert k == xs.size
+    probe = L * (rng.random(5000) * 3.0 - 1.0)               # from -L to 2 L
+    want = np.count_nonzero(np.mod(probe - (lo - 0.01), L) <= (hi - lo) + 0.02)
+    rest = [torch.as_tensor(L * rng.random(probe.size), device="cuda:0") for _ in range(3)]
+    assert mg.halo_select_device(torch.as_tensor(probe, device="cuda:0"), *rest, L, lo, hi, 0.01) == want
     # spread over the whole box: no gap wider than the block itself is found -> an interval that
     # still holds every particle
     xs = L * rng.random(100000)
