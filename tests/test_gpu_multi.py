@@ -116,8 +116,8 @@ def test_x_extent_is_the_complement_of_the_longest_gap(mg):
     assert mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L) == (0.0, pytest.approx(bin_w))
     # positions outside [0, L) are legal input (libnbpp folds them into the box): the interval is that
     # of the folded positions, and selecting with it finds the same particles as numpy does on them
-    xs = np.concatenate([-0.3 * L + 0.05 * L * rng.random(400), 1.2 * L + 0.05 * L * rng.random(400)])
-    folded = np.mod(xs, L)                                   # [0.7 L, 0.75 L) and [0.2 L, 0.25 L)
+    xs = np.concatenate([-0.3 * L + 0.05 * L * rng.random(400), 1.3 * L + 0.05 * L * rng.random(400)])
+    folded = np.mod(xs, L)                                   # [0.7 L, 0.75 L) and [0.3 L, 0.35 L)
     lo, hi = mg.x_extent_device(torch.as_tensor(xs, device="cuda:0"), L)
     assert lo < hi and folded.min() - bin_w <= lo <= folded.min() and folded.max() <= hi <= folded.max() + bin_w
     others = [torch.as_tensor(L * rng.random(xs.size), device="cuda:0") for _ in range(3)]
