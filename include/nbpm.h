@@ -96,6 +96,53 @@ int nbpm_accelerations_device(const nbpm_params* p, size_t n, const double* x, c
 int nbpm_accelerations(const nbpm_params* p, size_t n, const double* x, const double* y,
                        const double* z, const double* m, double* ax, double* ay, double* az);
 
+/*
+ * Initial conditions: the Zel'dovich displacement field on the mesh and the particles displaced by
+ * it, generated where the run will keep them.  Replaces compute_zeldovich_field after its white
+ * noise and initialize_dm (src/ics.cpp:68-216); the white noise itself stays the caller's
+ * (std::default_random_engine + std::normal_distribution on the host, src/ics.cpp:61-66: a stream
+ * the C++ library defines, which a device generator could not reproduce).
+ */
+typedef struct nbpm_ic_params {
+    int32_t mesh_size;      /* MESH_SIZE: cells per side of the displacement meshes          */
+    int32_t n_per_side;     /* N_PER_SIDE: particles per side of the lattice                 */
+    double domain_size;     /* DOMAIN_SIZE: the box in code units                            */
+    double box_size_mpc;    /* BOX_SIZE_MPC: the same length in Mpc                          */
+    double hubble_param;    /* h                                                             */
+    double omega_m;         /* Omega_m (the spectrum's shape parameter is Omega_m h)         */
+    double spectral_index;  /* n_s                                                           */
+    double amplitude;       /* A of P(k) = A k^n T(k)^2: nbpm_sigma8_amplitude               */
+    double scale_factor;    /* a at the start: the field is the displacement at that time    */
+} nbpm_ic_params;
+
+/*
+ * *amplitude = sigma_8^2 / (variance of the unnormalised spectrum in spheres of 8 Mpc/h), with
+ * the reference's own quadrature (src/ics.cpp:38-51: rectangle rule, k = 0.001 ... 100 h/Mpc in
+ * steps of 0.001).  Host arithmetic; needs no GPU and no nbpm_init.
+ */
+int nbpm_sigma8_amplitude(double sigma_8, double omega_m, double hubble_param, double spectral_index,
+                          double* amplitude);
+
+/*
+ * white_noise (mesh_size^3 unit Gaussians, DEVICE, preserved) -> dx, dy, dz (mesh_size^3 each,
+ * DEVICE, overwritten): forward transform, one kernel over the mesh_size^2 (mesh_size/2 + 1) modes
+ * (D_c = i c_c / c^2 sqrt(A P(k)) W, scaled to a discrete field and to the scale factor), three
+ * inverse transforms.  Replaces src/ics.cpp:68-156.
+ */
+int nbpm_zeldovich_field_device(const nbpm_ic_params* p, const double* white_noise, double* dx, double* dy,
+                                double* dz, void* stream);
+
+/*
+ * The n_per_side^3 particles: particle (a n + b) n + c starts at the centre of lattice cell
+ * (a, b, c), is displaced by the field value of the mesh cell that centre lies in, folded into
+ * [0, L), and gets the velocity velocity_factor * displacement (H f for Zel'dovich velocities,
+ * 0 for particles at rest) and mass `mass`.  All arrays DEVICE; m may be NULL.
+ * Replaces initialize_dm (src/ics.cpp:167-216).
+ */
+int nbpm_zeldovich_particles_device(const nbpm_ic_params* p, const double* dx, const double* dy, const double* dz,
+                                    double velocity_factor, double mass, double* x, double* y, double* z, double* vx,
+                                    double* vy, double* vz, double* m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,9 @@ struct Buf {
         cap = 0;
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), sizeof(double) * count));
         HIPCHK(hipMemset(p, 0, sizeof(double) * count));
+        // the fill runs on the null stream, which a caller's non-blocking stream does not wait for:
+        // without this wait it could land on top of the first data that stream copies in
+        HIPCHK(hipDeviceSynchronize());
         cap = count;
         return NBMG_OK;
     }

@@ -7,6 +7,8 @@
 //   hipFFT Z2D         phi_k -> phi              unnormalised, like the reference's c2r
 //   k_gradient         phi -> gx, gy, gz         central differences, periodic
 //   k_cic_interpolate  meshes -> acc             8 gathers per mesh per particle
+// and, once per run, the initial conditions: white noise -> D2Z -> k_displacement_modes -> 3 x Z2D ->
+// displacement meshes -> k_place_particles.
 // Each statement follows the reference's operation order so that everything but the two FFTs
 // and the order of the deposit's additions is bit for bit the reference's arithmetic
 // (compiled with -ffp-contract=off).
@@ -48,6 +50,7 @@ struct Ctx {
     int plan_n = 0;
     Buf spectrum, phi;                 // rho_k / phi_k (complex), phi (real)
     Buf rho, grav[3];                  // library-owned meshes of nbpm_accelerations_device
+    Buf ic_modes[3];                   // displacement coefficients of nbpm_zeldovich_field_device
     Buf host_in[4], host_acc[3];
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing = false;
@@ -244,6 +247,109 @@ __global__ void __launch_bounds__(WG) k_cic_interpolate(size_t n, const double* 
     az[i] = interp(gz);
 }
 
+// ---- initial conditions: Zel'dovich displacement field and the particles on it -------------------
+// Square root of the matter power spectrum's SHAPE at wavenumber kh (h / Mpc): kh^(n/2) T(q) with
+// the BBKS transfer function T(q) = ln(1 + 2.34 q) / (2.34 q) [1 + 3.89 q + (16.1 q)^2 + (5.46 q)^3
+// + (6.71 q)^4]^(-1/4), q = kh / (Omega_m h)   (the spectrum of src/ics.cpp:11-27, whose P(k) is the
+// square of this).  One function for the host quadrature and the mode kernel.
+struct SpectrumShape {
+    double inv_gamma;      // 1 / (Omega_m h)
+    double half_index;     // n_s / 2
+};
+__host__ __device__ inline double sqrt_power_shape(const SpectrumShape& sp, double kh) {
+    const double q = kh * sp.inv_gamma;
+    const double t = 2.34 * q;
+    // the bracket as a polynomial in q, by Horner's rule
+    constexpr double c2 = 16.1 * 16.1, c3 = 5.46 * 5.46 * 5.46, c4 = (6.71 * 6.71) * (6.71 * 6.71);
+    const double bracket = 1.0 + q * (3.89 + q * (c2 + q * (c3 + q * c4)));
+    const double transfer = log1p(t) / (t * sqrt(sqrt(bracket)));
+    return pow(kh, sp.half_index) * transfer;
+}
+
+// Fourier transform of the spherical top hat of radius R at x = k R.
+inline double tophat_window(double x) {
+    if (x < 1e-4) return 1.0 - x * x / 10.0;                // the series, where 3 (sin x - x cos x) / x^3 cancels
+    return 3.0 * (std::sin(x) - x * std::cos(x)) / (x * x * x);
+}
+
+// One thread per Fourier mode (i, j, k) of the half spectrum: the white-noise coefficient W becomes
+// the three displacement coefficients  D_c = i c_c / |c|^2 * sqrt(P(|k|)) * W * scale,  with c the
+// wave vector in code units (2 pi f / L), |k| the same vector in h / Mpc, and `scale` everything that
+// does not depend on the mode (sqrt(A M^3 / V_box) for the amplitude of a discrete field, a / M^3
+// for the growth factor and the unnormalised inverse transform).  i W = (-Im W, Re W).  The mean
+// mode is zero.  Frequencies follow src/ics.cpp:95-97: index M/2 counts as -M/2 along x and y and as
+// +M/2 along z (the half spectrum's last plane).
+__global__ void __launch_bounds__(WG) k_displacement_modes(int M, SpectrumShape sp, double kh_per_freq,
+                                                           double c_per_freq, double scale,
+                                                           const double2* __restrict__ noise,
+                                                           double2* __restrict__ dxk, double2* __restrict__ dyk,
+                                                           double2* __restrict__ dzk) {
+    const int nk = M / 2 + 1;
+    const size_t total = static_cast<size_t>(M) * M * nk;
+    const size_t idx = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    if (idx >= total) return;
+    const int k = static_cast<int>(idx % nk);
+    const int j = static_cast<int>((idx / nk) % M);
+    const int i = static_cast<int>(idx / (static_cast<size_t>(nk) * M));
+    const double f[3] = {static_cast<double>(i < M / 2 ? i : i - M), static_cast<double>(j < M / 2 ? j : j - M),
+                         static_cast<double>(k)};
+    const double f2 = f[0] * f[0] + f[1] * f[1] + f[2] * f[2];      // exact: small integers
+    double g = 0.0;
+    if (f2 > 0.0) {
+        const double kh = sqrt(f2) * kh_per_freq;
+        g = scale * sqrt_power_shape(sp, kh) / (f2 * c_per_freq * c_per_freq);
+    }
+    const double2 w = noise[idx];
+    const double re = -w.y * g, im = w.x * g;
+    dxk[idx] = make_double2(f[0] * c_per_freq * re, f[0] * c_per_freq * im);
+    dyk[idx] = make_double2(f[1] * c_per_freq * re, f[1] * c_per_freq * im);
+    dzk[idx] = make_double2(f[2] * c_per_freq * re, f[2] * c_per_freq * im);
+}
+
+// One thread per particle p = (a N + b) N + c of the N^3 lattice: it starts at the centre of its
+// lattice cell, is displaced by the field value of the MESH cell that centre lies in (truncation,
+// no interpolation: src/ics.cpp:181-191), folded into [0, L) with fmod(q + d + L, L) (:193-198) and
+// given the velocity `velocity_factor` * d (H f d, or 0 for particles at rest: :200-208).
+__global__ void __launch_bounds__(WG) k_place_particles(int N, int M, double L, double velocity_factor, double mass,
+                                                        const double* __restrict__ dx, const double* __restrict__ dy,
+                                                        const double* __restrict__ dz, double* __restrict__ x,
+                                                        double* __restrict__ y, double* __restrict__ z,
+                                                        double* __restrict__ vx, double* __restrict__ vy,
+                                                        double* __restrict__ vz, double* __restrict__ m) {
+    const size_t total = static_cast<size_t>(N) * N * N;
+    const size_t p = static_cast<size_t>(blockIdx.x) * WG + threadIdx.x;
+    if (p >= total) return;
+    const int lattice[3] = {static_cast<int>(p / (static_cast<size_t>(N) * N)), static_cast<int>((p / N) % N),
+                            static_cast<int>(p % N)};
+    const double spacing = L / N, cell = L / M;
+    double q[3];
+    size_t at = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q[a] = (lattice[a] + 0.5) * spacing;
+        at = at * M + static_cast<size_t>(static_cast<int>(q[a] / cell) % M);
+    }
+    const double d[3] = {dx[at], dy[at], dz[at]};
+    x[p] = fmod(q[0] + d[0] + L, L);
+    y[p] = fmod(q[1] + d[1] + L, L);
+    z[p] = fmod(q[2] + d[2] + L, L);
+    vx[p] = velocity_factor * d[0];
+    vy[p] = velocity_factor * d[1];
+    vz[p] = velocity_factor * d[2];
+    if (m) m[p] = mass;
+}
+
+int check_ic_params(const nbpm_ic_params* p) {
+    if (!p) return fail(NBPM_ERR_ARG, "params is NULL");
+    if (p->mesh_size < 2 || p->mesh_size > 1290) return fail(NBPM_ERR_ARG, "mesh_size must be in [2, 1290] (got %d)", p->mesh_size);
+    if (p->n_per_side < 0 || p->n_per_side > 1290) return fail(NBPM_ERR_ARG, "n_per_side must be in [0, 1290] (got %d)", p->n_per_side);
+    for (double v : {p->domain_size, p->box_size_mpc, p->hubble_param, p->omega_m})
+        if (!(v > 0.0) || !std::isfinite(v)) return fail(NBPM_ERR_ARG, "domain_size, box_size_mpc, hubble_param and omega_m must be positive and finite");
+    if (!std::isfinite(p->spectral_index) || !(p->amplitude >= 0.0) || !std::isfinite(p->amplitude) || !std::isfinite(p->scale_factor))
+        return fail(NBPM_ERR_ARG, "spectral_index, amplitude (>= 0) and scale_factor must be finite");
+    return NBPM_OK;
+}
+
 int check_params(const nbpm_params* p) {
     if (!p) return fail(NBPM_ERR_ARG, "params is NULL");
     if (!(p->domain_size > 0.0) || !std::isfinite(p->domain_size))
@@ -387,7 +493,8 @@ void nbpm_shutdown(void) {
         g.plan_n = 0;
     }
     for (Buf* b : {&g.spectrum, &g.phi, &g.rho, &g.grav[0], &g.grav[1], &g.grav[2], &g.host_in[0],
-                   &g.host_in[1], &g.host_in[2], &g.host_in[3], &g.host_acc[0], &g.host_acc[1], &g.host_acc[2]})
+                   &g.host_in[1], &g.host_in[2], &g.host_in[3], &g.host_acc[0], &g.host_acc[1], &g.host_acc[2],
+                   &g.ic_modes[0], &g.ic_modes[1], &g.ic_modes[2]})
         b->release();
     for (hipEvent_t& e : g.ev) {
         if (e) (void)hipEventDestroy(e);
@@ -458,6 +565,73 @@ int nbpm_accelerations_device(const nbpm_params* p, size_t n, const double* x, c
     CHK(check_params(p));
     if (n && (!x || !y || !z || !m || !ax || !ay || !az)) return fail(NBPM_ERR_ARG, "NULL array");
     return accelerations(p, n, x, y, z, m, ax, ay, az, static_cast<hipStream_t>(stream));
+}
+
+int nbpm_sigma8_amplitude(double sigma_8, double omega_m, double hubble_param, double spectral_index, double* amplitude) {
+    if (!amplitude) return fail(NBPM_ERR_ARG, "amplitude is NULL");
+    if (!(omega_m > 0.0) || !(hubble_param > 0.0) || !std::isfinite(sigma_8) || !std::isfinite(spectral_index))
+        return fail(NBPM_ERR_ARG, "omega_m and hubble_param must be positive, sigma_8 and spectral_index finite");
+    // variance of the unnormalised spectrum in spheres of 8 Mpc/h: (1 / 2 pi^2) * integral of P W^2 k^2 dk
+    // by the rectangle rule the reference defines its normalisation with (src/ics.cpp:38-51): nodes
+    // k = 0.001, 0.002, ... < 100, weight 0.001 each.  The terms are summed pairwise (blocks of 64).
+    const SpectrumShape sp{1.0 / (omega_m * hubble_param), 0.5 * spectral_index};
+    constexpr double dk = 0.001, R = 8.0;
+    constexpr int NODES = 99999;                            // 0.001 * 99999 = 99.999 < 100
+    double total = 0.0, block = 0.0;
+    for (int i = 1; i <= NODES; ++i) {
+        const double k = i * dk;
+        const double root = sqrt_power_shape(sp, k), w = tophat_window(k * R);
+        block += root * root * w * w * k * k * dk;
+        if (i % 64 == 0 || i == NODES) {
+            total += block;
+            block = 0.0;
+        }
+    }
+    *amplitude = sigma_8 * sigma_8 / (total / (2.0 * PI * PI));
+    return NBPM_OK;
+}
+
+int nbpm_zeldovich_field_device(const nbpm_ic_params* p, const double* white_noise, double* dx, double* dy,
+                                double* dz, void* stream) {
+    ENTER();
+    CHK(check_ic_params(p));
+    if (!white_noise || !dx || !dy || !dz) return fail(NBPM_ERR_ARG, "NULL array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = p->mesh_size;
+    const size_t modes = static_cast<size_t>(M) * M * (M / 2 + 1);
+    CHK(ensure_plans(M, s));
+    CHK(g.spectrum.ensure(sizeof(double2) * modes));
+    for (Buf& b : g.ic_modes) CHK(b.ensure(sizeof(double2) * modes));
+    double2* noise_k = g.spectrum.as<double2>();
+    FFTCHK(hipfftExecD2Z(g.r2c, const_cast<double*>(white_noise), reinterpret_cast<hipfftDoubleComplex*>(noise_k)));
+    const SpectrumShape sp{1.0 / (p->omega_m * p->hubble_param), 0.5 * p->spectral_index};
+    const double cells = static_cast<double>(M) * M * M;
+    const double box_volume = p->box_size_mpc * p->box_size_mpc * p->box_size_mpc;
+    // per-mode constants: amplitude of a discrete Gaussian field with spectrum A P(k) on M^3 cells of
+    // a box of that volume; growth factor a; 1 / M^3 of the unnormalised inverse transform
+    const double scale = std::sqrt(p->amplitude * cells / box_volume) * (p->scale_factor / cells);
+    hipLaunchKernelGGL(k_displacement_modes, dim3(cdiv(modes, WG)), dim3(WG), 0, s, M, sp,
+                       2.0 * PI / (p->box_size_mpc * p->hubble_param), 2.0 * PI / p->domain_size, scale, noise_k,
+                       g.ic_modes[0].as<double2>(), g.ic_modes[1].as<double2>(), g.ic_modes[2].as<double2>());
+    HIPCHK(hipGetLastError());
+    double* out[3] = {dx, dy, dz};
+    for (int c = 0; c < 3; ++c)
+        FFTCHK(hipfftExecZ2D(g.c2r, reinterpret_cast<hipfftDoubleComplex*>(g.ic_modes[c].as<double2>()), out[c]));
+    return NBPM_OK;
+}
+
+int nbpm_zeldovich_particles_device(const nbpm_ic_params* p, const double* dx, const double* dy, const double* dz,
+                                    double velocity_factor, double mass, double* x, double* y, double* z, double* vx,
+                                    double* vy, double* vz, double* m, void* stream) {
+    ENTER();
+    CHK(check_ic_params(p));
+    const size_t n = static_cast<size_t>(p->n_per_side) * p->n_per_side * p->n_per_side;
+    if (n == 0) return NBPM_OK;
+    if (!dx || !dy || !dz || !x || !y || !z || !vx || !vy || !vz) return fail(NBPM_ERR_ARG, "NULL array");
+    hipLaunchKernelGGL(k_place_particles, dim3(cdiv(n, WG)), dim3(WG), 0, static_cast<hipStream_t>(stream), p->n_per_side,
+                       p->mesh_size, p->domain_size, velocity_factor, mass, dx, dy, dz, x, y, z, vx, vy, vz, m);
+    HIPCHK(hipGetLastError());
+    return NBPM_OK;
 }
 
 int nbpm_accelerations(const nbpm_params* p, size_t n, const double* x, const double* y,
