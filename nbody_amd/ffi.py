@@ -257,6 +257,7 @@ MESH_EXPORTS = (
     "nbpm_init", "nbpm_shutdown", "nbpm_last_error", "nbpm_set_timing", "nbpm_get_stats",
     "nbpm_deposit_device", "nbpm_solve_device", "nbpm_potential_device", "nbpm_interpolate_device",
     "nbpm_accelerations_device", "nbpm_accelerations",
+    "nbpm_sigma8_amplitude", "nbpm_zeldovich_field_device", "nbpm_zeldovich_particles_device",
 )
 
 
@@ -264,6 +265,13 @@ class MeshParams(C.Structure):
     """nbpm_params."""
     _fields_ = [("domain_size", C.c_double), ("G", C.c_double), ("mesh_size", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class IcParams(C.Structure):
+    """nbpm_ic_params."""
+    _fields_ = [("mesh_size", C.c_int32), ("n_per_side", C.c_int32)] + [
+        (k, C.c_double) for k in ("domain_size", "box_size_mpc", "hubble_param", "omega_m", "spectral_index",
+                                  "amplitude", "scale_factor")]
 
 
 class MeshStats(C.Structure):
@@ -296,6 +304,10 @@ class MeshLibrary:
         L.nbpm_interpolate_device.argtypes = [P, C.c_size_t] + [_DP] * 9 + [C.c_void_p]
         L.nbpm_accelerations_device.argtypes = [P, C.c_size_t] + [_DP] * 7 + [C.c_void_p]
         L.nbpm_accelerations.argtypes = [P, C.c_size_t] + [_DP] * 7
+        L.nbpm_sigma8_amplitude.argtypes = [C.c_double] * 4 + [C.POINTER(C.c_double)]
+        IP = C.POINTER(IcParams)
+        L.nbpm_zeldovich_field_device.argtypes = [IP] + [_DP] * 4 + [C.c_void_p]
+        L.nbpm_zeldovich_particles_device.argtypes = [IP] + [_DP] * 3 + [C.c_double] * 2 + [_DP] * 7 + [C.c_void_p]
         self._inited = False
 
     def _check(self, rc):
@@ -352,6 +364,24 @@ class MeshLibrary:
         self._check(self.lib.nbpm_accelerations_device(
             C.byref(p), x.numel(), _dev(x), _dev(y), _dev(z), _dev(m), _dev(ax), _dev(ay),
             _dev(az), C.c_void_p(stream or 0)))
+
+    # initial conditions ------------------------------------------------------------
+    def sigma8_amplitude(self, sigma_8, omega_m, hubble_param, spectral_index):
+        """A of P(k) = A k^n T(k)^2 (nbpm_sigma8_amplitude; host arithmetic, no GPU needed)."""
+        a = C.c_double()
+        self._check(self.lib.nbpm_sigma8_amplitude(sigma_8, omega_m, hubble_param, spectral_index, C.byref(a)))
+        return a.value
+
+    def zeldovich_field_device(self, ip, white_noise, dx, dy, dz, stream=None):
+        """white noise (mesh^3 device tensor) -> the three displacement meshes (nbpm_zeldovich_field_device)."""
+        self._check(self.lib.nbpm_zeldovich_field_device(C.byref(ip), _dev(white_noise), _dev(dx), _dev(dy), _dev(dz),
+                                                         C.c_void_p(stream or 0)))
+
+    def zeldovich_particles_device(self, ip, disp, velocity_factor, mass, pos, vel, m=None, stream=None):
+        """The lattice particles displaced by the field (nbpm_zeldovich_particles_device)."""
+        self._check(self.lib.nbpm_zeldovich_particles_device(
+            C.byref(ip), *[_dev(d) for d in disp], velocity_factor, mass, *[_dev(a) for a in pos],
+            *[_dev(a) for a in vel], _dev(m) if m is not None else None, C.c_void_p(stream or 0)))
 
     def accelerations(self, p, x, y, z, m, ax, ay, az):
         """Host numpy arrays; ax/ay/az are overwritten (nbpm_accelerations)."""

@@ -29,7 +29,23 @@ void nbmg_check(int rc) {
 
 DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const ZeldovichField* field)
     : config_(config) {
-    n_ = n_total_ = s.num_particles;
+    const double* state[10] = {s.pos_x.data(), s.pos_y.data(), s.pos_z.data(), s.vel_x.data(), s.vel_y.data(),
+                               s.vel_z.data(), s.acc_x.data(), s.acc_y.data(), s.acc_z.data(), s.mass.data()};
+    construct(s.num_particles, state, field);
+}
+
+DeviceEngine::DeviceEngine(const Config& config, const DeviceParticles& s, const ZeldovichField* field)
+    : config_(config) {
+    // accelerations start at zero, as add_particle leaves them (src/particles.cpp:32-45)
+    const double* state[10] = {s.x.data(), s.y.data(), s.z.data(), s.vx.data(), s.vy.data(),
+                               s.vz.data(), nullptr, nullptr, nullptr, s.m.data()};
+    construct(s.count, state, field);
+}
+
+// `state`: x y z vx vy vz ax ay az m of ALL particles, host or device memory (the copies find out
+// which); a null entry stands for zeros.
+void DeviceEngine::construct(std::size_t n_total, const double* const (&state)[10], const ZeldovichField* field) {
+    n_ = n_total_ = n_total;
     ranks_ = nbmg_nranks();
     std::size_t padded = std::max<std::size_t>(n_total_, 1);
     if (ranks_ > 0) {
@@ -37,16 +53,16 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
         padded = std::max<std::size_t>(nbmg_padded_length(n_total_, ranks_), 1);
     }
     cells_ = static_cast<std::size_t>(config_.MESH_SIZE) * config_.MESH_SIZE * config_.MESH_SIZE;
-    const std::vector<double>* host[10] = {&s.pos_x, &s.pos_y, &s.pos_z, &s.vel_x, &s.vel_y,
-                                           &s.vel_z, &s.acc_x, &s.acc_y, &s.acc_z, &s.mass};
     for (int c = 0; c < 9; ++c) {      // this process's block of the per-particle state
         hip_check(hipMalloc(reinterpret_cast<void**>(&dev_[c]), sizeof(double) * std::max<std::size_t>(n_, 1)), "hipMalloc");
-        if (n_) hip_check(hipMemcpy(dev_[c], host[c]->data() + begin_, sizeof(double) * n_, hipMemcpyHostToDevice), "upload");
+        if (n_ && state[c]) hip_check(hipMemcpy(dev_[c], state[c] + begin_, sizeof(double) * n_, hipMemcpyDefault), "copy in");
+        else if (n_) hip_check(hipMemset(dev_[c], 0, sizeof(double) * n_), "hipMemset");
     }
     // masses of ALL particles (the sources of the pair force), in a padded array
     hip_check(hipMalloc(reinterpret_cast<void**>(&dev_[9]), sizeof(double) * padded), "hipMalloc");
     hip_check(hipMemset(dev_[9], 0, sizeof(double) * padded), "hipMemset");
-    if (n_total_) hip_check(hipMemcpy(dev_[9], s.mass.data(), sizeof(double) * n_total_, hipMemcpyHostToDevice), "upload");
+    if (n_total_) hip_check(hipMemcpy(dev_[9], state[9], sizeof(double) * n_total_, hipMemcpyDefault), "copy in");
+    hip_check(hipDeviceSynchronize(), "sync");   // the fills ran on the null stream, the engine's stream does not wait for it
     if (ranks_ > 1) hip_check(hipMalloc(reinterpret_cast<void**>(&gather_), sizeof(double) * padded), "hipMalloc");
     int device = 0;
     hip_check(hipGetDevice(&device), "hipGetDevice");
@@ -74,16 +90,17 @@ DeviceEngine::DeviceEngine(const Config& config, const ParticleSystem& s, const 
     cosmo.total_time = 0.0;
     update_cosmology(cosmo, config_);
     if (config_.USE_HYDRO) {                                                 // src/ics.cpp:241-288
-        if (!field || field->dx.size() != cells_)
+        if (!field || field->dx.size() != cells_ || field->dy.size() != cells_ || field->dz.size() != cells_)
             throw std::runtime_error("USE_HYDRO needs the displacement field of the initial conditions");
         if (n_total_ == 0) throw std::runtime_error("USE_HYDRO needs dark-matter particles (src/ics.cpp:250)");
         nbgas_check(nbgas_init(device));
         for (double*& m : gas_) hip_check(hipMalloc(reinterpret_cast<void**>(&m), sizeof(double) * cells_), "hipMalloc");
         deposit_density();
         // the displacement field is only needed now: stage it in the gravity meshes
-        const std::vector<double>* disp[3] = {&field->dx, &field->dy, &field->dz};
+        const double* disp[3] = {field->dx.data(), field->dy.data(), field->dz.data()};
         for (int c = 0; c < 3; ++c)
-            hip_check(hipMemcpy(mesh_[2 + c], disp[c]->data(), sizeof(double) * cells_, hipMemcpyHostToDevice), "upload");
+            hip_check(hipMemcpyAsync(mesh_[2 + c], disp[c], sizeof(double) * cells_, hipMemcpyDeviceToDevice,
+                                     static_cast<hipStream_t>(main_)), "stage displacement");
         const double total_dm_mass = n_total_ * config_.DM_PARTICLE_MASS;    // :251-252
         const double mass_ratio = config_.GAS_TOTAL_MASS / total_dm_mass;
         const double u0 = internal_energy_from_temperature(config_.INITIAL_GAS_TEMPERATURE_K, config_.HUBBLE_PARAM,

@@ -33,6 +33,9 @@ class DeviceEngine {
     // USE_HYDRO the gas starts from the displacement field `field` (src/ics.cpp:241-288), which
     // must then be given.
     DeviceEngine(const Config& config, const ParticleSystem& initial, const ZeldovichField* field = nullptr);
+    // The same from initial conditions that were generated on the device (initialize_particles_device):
+    // nothing passes through host memory.
+    DeviceEngine(const Config& config, const DeviceParticles& initial, const ZeldovichField* field = nullptr);
     ~DeviceEngine();
     DeviceEngine(const DeviceEngine&) = delete;
     DeviceEngine& operator=(const DeviceEngine&) = delete;
@@ -77,6 +80,7 @@ class DeviceEngine {
     bool overlap_forces = true;
 
    private:
+    void construct(std::size_t n_total, const double* const (&state)[10], const ZeldovichField* field);
     void compute_accelerations();        // src/integrator.cpp:236-269
     void deposit_density();
     bool launch_short_range();           // the overlapped short-range force, on its own stream

@@ -1,7 +1,12 @@
 #include "integrator.hpp"
 
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
 #include <cmath>
+#include <initializer_list>
+#include <stdexcept>
+#include <string>
 
 namespace nbh {
 
@@ -29,36 +34,100 @@ void update_cosmology(Cosmology& c, const Config& config) {
     c.hubble_param = H0 * std::sqrt(Om / a3 + Ol);
 }
 
-void apply_dm_kick(ParticleSystem& dm, double dt, double a, double H) {
-    const double a3 = a * a * a;
-    const double dt_over_a3 = dt / a3;
-    const double dt_2H = dt * 2.0 * H;
-    for (std::size_t i = 0; i < dm.num_particles; ++i) {
-        dm.vel_x[i] += dm.acc_x[i] * dt_over_a3 - dm.vel_x[i] * dt_2H;
-        dm.vel_y[i] += dm.acc_y[i] * dt_over_a3 - dm.vel_y[i] * dt_2H;
-        dm.vel_z[i] += dm.acc_z[i] * dt_over_a3 - dm.vel_z[i] * dt_2H;
+// ---- kick, drift and max |a|^2 of a HOST-resident ParticleSystem ---------------------------------
+// The arithmetic of src/integrator.cpp:168-213 exists once in this code base, as device kernels
+// behind nbpp_kick_device / nbpp_kick_drift_device / nbpp_max_accel_sq_device.  A caller that keeps
+// its state in host vectors, as the reference does, gets the same kernels through a device mirror
+// of the arrays a call touches: up, one kernel, down.  (The engine proper never takes this path: its
+// state lives in HBM, DeviceEngine.)
+namespace {
+
+void hip_ok(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+void nbpp_ok(int rc) {
+    if (rc != NBPP_OK) throw std::runtime_error(std::string("libnbpp: ") + nbpp_last_error());
+}
+
+class Mirror {   // device copies of position, velocity and acceleration, grown on demand
+   public:
+    ~Mirror() {
+        for (double* p : dev_)
+            if (p) (void)hipFree(p);
+        if (stream_) (void)hipStreamDestroy(stream_);
     }
+    void* stream() {   // copies and kernels of one call are ordered on one stream of the mirror's own
+        if (!stream_) hip_ok(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+        return stream_;
+    }
+    enum Field { X = 0, V = 3, A = 6 };
+    double* operator[](int c) const { return dev_[c]; }
+    void up(std::size_t n, std::vector<double>* const (&host)[9], std::initializer_list<Field> fields) {
+        if (n > cap_) {
+            for (double*& p : dev_) {
+                if (p) hip_ok(hipFree(p), "hipFree");
+                p = nullptr;
+                hip_ok(hipMalloc(reinterpret_cast<void**>(&p), sizeof(double) * n), "hipMalloc");
+            }
+            cap_ = n;
+        }
+        for (Field f : fields)
+            for (int c = f; c < f + 3; ++c)
+                hip_ok(hipMemcpyAsync(dev_[c], host[c]->data(), sizeof(double) * n, hipMemcpyHostToDevice,
+                                      static_cast<hipStream_t>(stream())), "upload");
+    }
+    void down(std::size_t n, std::vector<double>* const (&host)[9], std::initializer_list<Field> fields) {
+        for (Field f : fields)
+            for (int c = f; c < f + 3; ++c)
+                hip_ok(hipMemcpyAsync(host[c]->data(), dev_[c], sizeof(double) * n, hipMemcpyDeviceToHost,
+                                      static_cast<hipStream_t>(stream())), "download");
+        hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream())), "sync");
+    }
+
+   private:
+    double* dev_[9] = {};
+    std::size_t cap_ = 0;
+    hipStream_t stream_ = nullptr;
+};
+
+Mirror& mirror() {
+    static Mirror m;
+    return m;
+}
+
+}  // namespace
+
+#define STATE_OF(dm)                                                                                         \
+    std::vector<double>* const state[9] = {&(dm).pos_x, &(dm).pos_y, &(dm).pos_z, &(dm).vel_x, &(dm).vel_y, \
+                                           &(dm).vel_z, &(dm).acc_x, &(dm).acc_y, &(dm).acc_z}
+
+void apply_dm_kick(ParticleSystem& dm, double dt, double a, double H) {
+    const std::size_t n = dm.num_particles;
+    if (!n) return;
+    STATE_OF(dm);
+    Mirror& d = mirror();
+    d.up(n, state, {Mirror::V, Mirror::A});
+    nbpp_ok(nbpp_kick_device(n, d[3], d[4], d[5], d[6], d[7], d[8], dt, a, H, d.stream()));
+    d.down(n, state, {Mirror::V});
 }
 
 void apply_dm_drift(ParticleSystem& dm, double dt, double domain_size) {
-    const double inv_domain = 1.0 / domain_size;
-    for (std::size_t i = 0; i < dm.num_particles; ++i) {
-        const double nx = dm.pos_x[i] + dm.vel_x[i] * dt;
-        const double ny = dm.pos_y[i] + dm.vel_y[i] * dt;
-        const double nz = dm.pos_z[i] + dm.vel_z[i] * dt;
-        dm.pos_x[i] = nx - domain_size * std::floor(nx * inv_domain);
-        dm.pos_y[i] = ny - domain_size * std::floor(ny * inv_domain);
-        dm.pos_z[i] = nz - domain_size * std::floor(nz * inv_domain);
-    }
+    const std::size_t n = dm.num_particles;
+    if (!n) return;
+    STATE_OF(dm);
+    Mirror& d = mirror();
+    d.up(n, state, {Mirror::X, Mirror::V});
+    nbpp_ok(nbpp_drift_device(n, d[0], d[1], d[2], d[3], d[4], d[5], dt, domain_size, d.stream()));
+    d.down(n, state, {Mirror::X});
 }
 
 void calculate_max_acceleration(ParticleSystem& dm) {
-    double local_max = 1e-9;
-    for (std::size_t i = 0; i < dm.num_particles; ++i) {
-        const double s = dm.acc_x[i] * dm.acc_x[i] + dm.acc_y[i] * dm.acc_y[i] + dm.acc_z[i] * dm.acc_z[i];
-        local_max = (s > local_max) ? s : local_max;
-    }
-    dm.max_accel_sq = local_max;
+    const std::size_t n = dm.num_particles;
+    STATE_OF(dm);
+    Mirror& d = mirror();
+    if (n) d.up(n, state, {Mirror::A});
+    // (no particles: the floor, 1e-9)
+    nbpp_ok(nbpp_max_accel_sq_device(n, d[6], d[7], d[8], &dm.max_accel_sq, d.stream()));
 }
 
 void compute_accelerations(ParticleSystem& dm, const Config& config) {

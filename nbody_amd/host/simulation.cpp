@@ -15,7 +15,8 @@ static bool writer_rank();
 Simulation::Simulation(const Config& config, const RunOptions& options) : config_(config), options_(options) {
     Cosmology cosmo;
     ZeldovichField field;
-    ParticleSystem dm = initialize_particles(config_, cosmo, &field);
+    // field and particles are generated on the device and stay there
+    const DeviceParticles dm = initialize_particles_device(config_, cosmo, &field);
     engine_.reset(new DeviceEngine(config_, dm, config_.USE_HYDRO ? &field : nullptr));
     engine_->overlap_forces = options_.overlap_forces;
     // device times are for the log: none are taken when nothing is logged

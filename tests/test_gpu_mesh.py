@@ -239,3 +239,48 @@ def test_potential_of_the_last_solve(mesh):
     assert rel_to_max(phi, ref) < TOL
     with pytest.raises(ffi.NbppError):
         mesh.potential_device(params(M + 1, L, G), torch.zeros((M + 1) ** 3, dtype=torch.float64, device="cuda:0"))
+
+
+@pytest.mark.parametrize("n_side,mesh,seed,standing", [(20, 20, 3, False), (12, 18, 5, False), (16, 16, 42, True)])
+def test_initial_conditions_on_the_device_match_the_oracle(n_side, mesh, seed, standing):
+    """nbpm_zeldovich_field_device + nbpm_zeldovich_particles_device through the C ABI, fed with the
+    white noise of libstdc++'s stream (the oracle's C restatement of it), against the numpy pipeline
+    of oracle/zeldovich.py: displacement meshes, positions and velocities.  Mesh and lattice of
+    different sizes exercise the cell look-up; `standing` the particles at rest (src/ics.cpp:200-208)."""
+    import ctypes as C
+    import nbody_amd
+    from nbody_amd import ffi
+    from oracle.oracle import Oracle, _dp
+    from oracle.zeldovich import zeldovich_particles
+    lib = nbody_amd.load_mesh(device=0)
+    pos, vel, info = zeldovich_particles(n_per_side=n_side, mesh_size=mesh, seed=seed)
+    orc = Oracle()
+    orc.lib.orc_libstdcxx_normal_field.argtypes = [C.c_uint32, C.c_size_t, C.POINTER(C.c_double)]
+    white = np.empty(mesh ** 3)
+    orc.lib.orc_libstdcxx_normal_field(seed, white.size, _dp(white))
+    ip = ffi.IcParams(mesh_size=mesh, n_per_side=n_side, domain_size=1.0, box_size_mpc=16.0, hubble_param=0.7,
+                      omega_m=0.3, spectral_index=0.96, scale_factor=info["scale_factor"],
+                      amplitude=lib.sigma8_amplitude(0.81, 0.3, 0.7, 0.96))
+    assert ip.amplitude == pytest.approx(info["A"], rel=1e-12)
+    noise = torch.as_tensor(white, device="cuda:0")
+    disp = [torch.empty(mesh ** 3, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    lib.zeldovich_field_device(ip, noise, *disp)
+    torch.cuda.synchronize()
+    assert np.array_equal(noise.cpu().numpy(), white)                       # the input is preserved
+    scale = max(float(np.max(np.abs(d))) for d in info["displacement"])
+    for got, want in zip(disp, info["displacement"]):
+        assert np.max(np.abs(got.cpu().numpy().reshape(mesh, mesh, mesh) - want)) < 1e-12 * scale
+    n = n_side ** 3
+    out = [torch.full((n,), -7.0, dtype=torch.float64, device="cuda:0") for _ in range(7)]
+    factor = 0.0 if standing else info["hubble_param"] * info["growth_f"]
+    lib.zeldovich_particles_device(ip, disp, factor, 0.125, out[:3], out[3:6], m=out[6])
+    torch.cuda.synchronize()
+    for c in range(3):
+        d = np.abs(out[c].cpu().numpy() - pos[c])
+        assert np.max(np.minimum(d, 1.0 - d)) < 1e-13                       # either side of the wrap
+        if standing:
+            assert not out[3 + c].any()
+        else:
+            assert np.max(np.abs(out[3 + c].cpu().numpy() - vel[c])) < 1e-11 * np.max(np.abs(vel[c]))
+    assert torch.all(out[6] == 0.125)
+    assert all(0.0 <= float(o.min()) and float(o.max()) < 1.0 for o in out[:3])
