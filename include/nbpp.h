@@ -207,6 +207,16 @@ void nbpp_host_free(void* p);
  * hipHostRegister): the library then keeps to the kernels that write their sums with plain
  * stores (the pair-once direct-summation kernel adds with fp64 atomics, which are only
  * guaranteed for ordinary device allocations, and is not chosen for such outputs).
+ *
+ * Concurrency.  The library's working memory (sorted copies, cell lists, queues, partial sums) is
+ * one set per process.  Calls may come from several host threads (they are serialised on a lock
+ * for the time it takes to queue them) and on several streams: a compute call whose predecessor
+ * ran on a different stream first makes its stream wait for that predecessor's kernels
+ * (hipStreamWaitEvent on an event the library records behind every compute call), so results are
+ * correct on any mix of streams; the device work of two compute calls never overlaps.  Work of
+ * OTHER kinds on other streams overlaps with a compute call as usual.  This holds for
+ * nbpp_accumulate_device, nbpp_accumulate_pairs_device, nbpp_accumulate_device_noalloc and
+ * nbpp_accumulate alike.  nbpp_get_stats describes the call that was queued last.
  */
 int nbpp_accumulate_device(const nbpp_params* p, size_t n_src,
                            const double* x, const double* y, const double* z,
@@ -225,8 +235,9 @@ int nbpp_accumulate_device(const nbpp_params* p, size_t n_src,
  * Limits: n <= NBPP_NOALLOC_MAX_N, else NBPP_ERR_RANGE; parameters whose search grid does not
  * fit the array (a cutoff radius far below the particle spacing) also give NBPP_ERR_RANGE with
  * the sizes in the message, and nothing has been added to ax, ay, az then.
- * All calls on one GPU share the array: two such calls must not overlap in time (issue them on
- * one stream, or order the streams), or they overwrite each other's work.
+ * All calls on one GPU share the array and keep what the last call left in it; the library orders
+ * them itself (see "Concurrency" above: a call on another stream waits for the one before it), so
+ * two such calls never run at the same time.
  */
 #define NBPP_NOALLOC_MAX_N 262144                      /* 64^3 particles */
 #define NBPP_NOALLOC_SCRATCH_BYTES (48u * 1024u * 1024u)

@@ -147,6 +147,14 @@ struct Ctx : Work {
     int64_t opt_force_kernel = 0, opt_timing = 0, opt_force_i = 0, opt_force_split = 0,
             opt_p3m_radius = 0, opt_no_uniform = 0, opt_deterministic = 0, opt_p3m_lanes = 0, opt_p3m_pooled = 0, opt_p3m_sym = 0, opt_pool_wg = 0, opt_row_lanes = 0, opt_rows_pooled = 0;
     nbpp_stats stats{};
+    // The working buffers are ONE set per process, and a compute call returns while its kernels are
+    // still running.  A later call on another stream would overwrite them under those kernels, so every
+    // compute call leaves an event behind and the next one, if it comes on a different stream, makes
+    // its stream wait for it: calls from several streams are correct, their device work just does
+    // not overlap.
+    hipEvent_t busy = nullptr;
+    hipStream_t busy_stream = nullptr;
+    bool busy_recorded = false;
 };
 
 Ctx g;
@@ -181,10 +189,13 @@ int check_params(const nbpp_params* p) {
     if (p->use_pm) {
         // trans_width == 0 (cutoff_transition_width_factor = 0) is legal in the reference: r_switch
         // then equals the cutoff radius and no accepted pair reaches the taper's division
-        if (!(p->cutoff_sq > 0.0) || !(p->trans_width >= 0.0) || !(p->pm_soft_sq >= 0.0) ||
+        // pm_soft_sq is (cell / 2)^2 in the reference (src/particles.cpp:146-147), never zero; the
+        // pooled kernels evaluate a target's own record and rely on (r^2 + pm_soft_sq)^(-3/2) being
+        // finite at r = 0 for that record to add exactly nothing
+        if (!(p->cutoff_sq > 0.0) || !(p->trans_width >= 0.0) || !(p->pm_soft_sq > 0.0) ||
             !(p->r_switch >= 0.0))
             return fail(NBPP_ERR_ARG,
-                        "use_pm needs cutoff_sq > 0, trans_width >= 0, pm_soft_sq >= 0, "
+                        "use_pm needs cutoff_sq > 0, trans_width >= 0, pm_soft_sq > 0, "
                         "r_switch >= 0");
     }
     return NBPP_OK;
@@ -802,11 +813,32 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     return NBPP_OK;
 }
 
+int compute_in_order(const nbpp_params* p, size_t n_src, const double* x, const double* y,
+                     const double* z, const double* m, size_t tgt_begin, size_t n_tgt,
+                     double* ax, double* ay, double* az, hipStream_t s, int sym_part, int sym_parts);
+
+// Every compute entry point ends up here, holding g_mu.
 int compute_on_device(const nbpp_params* p, size_t n_src, const double* x, const double* y,
                       const double* z, const double* m, size_t tgt_begin, size_t n_tgt,
                       double* ax, double* ay, double* az, hipStream_t s, int sym_part = -1,
                       int sym_parts = 1) {
     if (n_src > 0x7fffff00ULL) return fail(NBPP_ERR_RANGE, "n_src exceeds 2^31 - 256");
+    if (g.busy_recorded && g.busy_stream != s) HIPCHK(hipStreamWaitEvent(s, g.busy, 0));
+    const int rc = compute_in_order(p, n_src, x, y, z, m, tgt_begin, n_tgt, ax, ay, az, s, sym_part, sym_parts);
+    // (also after a failure: whatever was queued before it may still be running)
+    if (hipEventRecord(g.busy, s) == hipSuccess) {
+        g.busy_stream = s;
+        g.busy_recorded = true;
+    } else {
+        (void)hipGetLastError();
+        if (rc == NBPP_OK) return fail(NBPP_ERR_HIP, "hipEventRecord failed after the compute call");
+    }
+    return rc;
+}
+
+int compute_in_order(const nbpp_params* p, size_t n_src, const double* x, const double* y,
+                     const double* z, const double* m, size_t tgt_begin, size_t n_tgt,
+                     double* ax, double* ay, double* az, hipStream_t s, int sym_part, int sym_parts) {
     g.stats = nbpp_stats{};
     g.stats.n_sources = n_src;
     g.stats.n_targets = n_tgt;
@@ -896,6 +928,8 @@ int nbpp_init(int device) {
                     prop.gcnArchName);
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     for (auto& e : g.ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&g.busy, hipEventDisableTiming));
+    g.busy_recorded = false;
     HIPCHK(hipHostMalloc(&g.pinned, 8192, hipHostMallocDefault));
     // this device's copy of the fixed workspace (the device was made current above)
     void* fixed = nullptr;
@@ -919,6 +953,9 @@ void nbpp_shutdown(void) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
+    if (g.busy) (void)hipEventDestroy(g.busy);
+    g.busy = nullptr;
+    g.busy_recorded = false;
     (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
     if (g.pinned) (void)hipHostFree(g.pinned);
@@ -930,6 +967,7 @@ void nbpp_shutdown(void) {
 }
 
 int nbpp_set_option(int key, int64_t value) {
+    std::lock_guard<std::mutex> lock(g_mu);   // options are read by compute calls, which hold the same lock
     switch (key) {
         case NBPP_OPT_FORCE_KERNEL: g.opt_force_kernel = value; return NBPP_OK;
         case NBPP_OPT_TIMING: g.opt_timing = value; return NBPP_OK;
@@ -943,7 +981,7 @@ int nbpp_set_option(int key, int64_t value) {
         case NBPP_OPT_P3M_PAIR_ONCE: g.opt_p3m_sym = value; return NBPP_OK;
         case NBPP_OPT_P3M_ROW_LANES:
             if (value != 0 && value != -1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
-                return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_ROW_LANES takes 0, -1, 8, 16, 32 or 64");
+                return fail(NBPP_ERR_ARG, "NBPP_OPT_P3M_ROW_LANES takes 0, -1, 2, 4, 8, 16, 32 or 64");
             g.opt_row_lanes = value;
             return NBPP_OK;
         case NBPP_OPT_P3M_ROWS_POOLED: g.opt_rows_pooled = value; return NBPP_OK;
@@ -958,6 +996,7 @@ int nbpp_set_option(int key, int64_t value) {
 
 int nbpp_get_stats(nbpp_stats* out) {
     if (!out) return fail(NBPP_ERR_ARG, "out is NULL");
+    std::lock_guard<std::mutex> lock(g_mu);
     *out = g.stats;
     return NBPP_OK;
 }

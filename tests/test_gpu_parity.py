@@ -1260,3 +1260,38 @@ def test_p3m_pair_once_falls_back_on_a_clustered_set(lib):
         assert lib.stats()["p3m_pooled"] != 2
     finally:
         lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
+
+
+@pytest.mark.parametrize("use_pm", [True, False])
+def test_compute_calls_on_two_streams_do_not_disturb_each_other(lib, use_pm):
+    """The library's working buffers are one set per process.  Two compute calls queued back to
+    back on two different non-blocking streams, with nothing in the caller's code ordering them, must
+    both give the result of a call made alone: the library makes the second stream wait for the
+    first call's kernels."""
+    n_side = 64 if use_pm else 40
+    n = n_side ** 3
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm).pp_params()
+    sets = []
+    for seed in (5, 6):
+        pos = datasets.jittered_lattice(n_side, seed=seed)
+        sets.append([torch.as_tensor(a, device="cuda:0") for a in (*pos, datasets.masses(n, equal=True))])
+    lib.set_option(ffi.OPT_DETERMINISTIC, 1)     # reproducible kernels: equality can be exact
+    try:
+        alone = []
+        for d in sets:
+            acc = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+            lib.accumulate_device(p, *d, *acc)
+            torch.cuda.synchronize()
+            alone.append(acc)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for _ in range(3):
+            got = [[torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)] for _ in sets]
+            torch.cuda.synchronize()
+            for d, acc, st in zip(sets, got, streams):
+                lib.accumulate_device(p, *d, *acc, stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            for acc, want in zip(got, alone):
+                for a, w in zip(acc, want):
+                    assert torch.equal(a, w)
+    finally:
+        lib.set_option(ffi.OPT_DETERMINISTIC, 0)
