@@ -81,11 +81,7 @@ def test_pair_shares_of_eight_ranks_add_up_to_the_whole_force_at_128_cubed(lib, 
     pairs = 0
     for rank in range(ranks):
         sums = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
-        lib.set_option(ffi.OPT_TIMING, 1)
-        try:
-            lib.accumulate_pairs_device(p, x, y, z, mm, *sums, part=rank, n_parts=ranks)
-        finally:
-            lib.set_option(ffi.OPT_TIMING, 0)
+        lib.accumulate_pairs_device(p, x, y, z, mm, *sums, part=rank, n_parts=ranks)
         torch.cuda.synchronize()
         st = lib.stats()
         assert st["kernel_variant"] == ffi.KERNEL_DIRECT_SYMMETRIC
