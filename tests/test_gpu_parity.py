@@ -1268,6 +1268,7 @@ def test_compute_calls_on_two_streams_do_not_disturb_each_other(lib, use_pm):
     back on two different non-blocking streams, with nothing in the caller's code ordering them, must
     both give the result of a call made alone: the library makes the second stream wait for the
     first call's kernels."""
+    import torch
     n_side = 64 if use_pm else 40
     n = n_side ** 3
     p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm).pp_params()
