@@ -532,7 +532,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     int n_entries = 0;
     double occupancy = 1.0;
     // bricks of the pair-once kernel (k_p3m_sym) and the fullest brick's region
-    const int nbx = cdiv(nside, SYM_BX), nby = cdiv(nside, SYM_BY), nbz = cdiv(nside, SYM_BZ);
+    const SymBrick brick = sym_brick(R);
+    const int nbx = cdiv(nside, brick.bx), nby = cdiv(nside, brick.by), nbz = cdiv(nside, brick.bz);
     unsigned long long region_max = ~0ull;
     {
         CHK(g.counter.ensure(4 * sizeof(unsigned long long)));
@@ -546,13 +547,13 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         const bool sym_rested = g.opt_p3m_sym == 0 && g.sym_skip_left > 0;
         if (sym_rested) --g.sym_skip_left;
         // (nor by itself below 2^16 targets, which always get several lanes each: see `lanes` below)
-        const bool sym_possible = all_targets && R <= SYM_MAXR && !sym_rested &&
+        const bool sym_possible = all_targets && sym_brick_fits(brick, R) && !sym_rested &&
                                   (g.opt_p3m_sym > 0 ||
                                    (g.opt_p3m_sym == 0 && g.last_occupancy < 6.5 && n_tgt >= 65536 && !g.opt_deterministic &&
                                     (g.opt_p3m_lanes == 0 || g.opt_p3m_lanes == 1)));
         if (sym_possible)
             hipLaunchKernelGGL(k_sym_region_max, dim3(cdiv(1LL * nbx * nby * nbz, WG)), dim3(WG), 0, s, grid, start,
-                               nbx, nby, nbz, occ + 2);
+                               brick, nbx, nby, nbz, occ + 2);
         unsigned long long* host = static_cast<unsigned long long*>(g.pinned);
         HIPCHK(hipMemcpyAsync(host, occ, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipEventRecord(g.ev[3], s));
@@ -640,7 +641,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
                                n_entries + P3M_POOL_TRIP < (1 << P3M_POOL_LANE_SHIFT);
     bool rows_pool = rows_pool_can && g.opt_rows_pooled > 0 && row_lanes >= 2 && row_lanes <= 16;
     const bool sym = row_lanes == 0 && all_targets && region_max <= static_cast<unsigned long long>(SYM_CAP) && !wide && table_fits &&
-                     n_entries + P3M_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
+                     n_entries + SYM_TRIP < (1 << SYM_JBITS) && all_device(ax, ay, az) &&
                      (g.opt_p3m_sym > 0 ||
                       (g.opt_p3m_sym == 0 && !g.opt_deterministic && lanes == 1 && occupancy < 6.0));
     // one lane per target: the survivors of the filter are pooled per wavefront and evaluated 64
@@ -672,7 +673,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     uint8_t* codes = g.ghostcode.as<uint8_t>();
     double4* rec = g.src.x.as<double4>();
     // and their fp32 copies, one array per axis, in the y buffer
-    const size_t f_stride = (static_cast<size_t>(n_entries) + std::max(P3M_TRIP, P3M_POOL_TRIP) + 63) / 64 * 64;
+    const size_t f_stride = (static_cast<size_t>(n_entries) + std::max({P3M_TRIP, P3M_POOL_TRIP, SYM_TRIP}) + 63) / 64 * 64;
     CHK(g.src.y.ensure(sizeof(float) * 3 * f_stride));
     float* fx = g.src.y.as<float>();
     float* fy = fx + f_stride;
@@ -685,8 +686,25 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
         CHK(canonical_order(static_cast<int>(ncell), n_entries, start, entries, g.src.cell.as<int>(),
                             g.src.rank.as<int>(), s));
     }
-    hipLaunchKernelGGL(k_ghost_gather, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
-                       x, y, z, m, p->G, p->domain_size, rec, fx, fy, fz);
+    // k_p3m_sym takes the candidates' positions as 16-bit integers instead (SymQuant): the same buffer,
+    // x | y << 16 in the first n_entries + 8 words, z in half words behind them.  The range covers the
+    // ghost layers and half a cell more; two positions r apart differ by at most r * scale + sqrt(3).
+    SymQuant quant{0.0, 1.0};
+    uint32_t* qxy = reinterpret_cast<uint32_t*>(fx);
+    uint16_t* qz = reinterpret_cast<uint16_t*>(qxy + f_stride);
+    int qbound = 0;
+    if (sym) {
+        const double cell = p->domain_size / nside, margin = (R + 0.5) * cell;
+        quant.lo = -margin;
+        quant.scale = 65535.0 / (p->domain_size + 2.0 * margin);
+        const double reach = std::sqrt(p->cutoff_sq) * quant.scale + 1.7320508075688773 + 1e-6;
+        qbound = static_cast<int>(std::floor(reach * reach)) + 1;
+        hipLaunchKernelGGL(k_ghost_gather<true>, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
+                           x, y, z, m, p->G, p->domain_size, rec, fx, fy, fz, quant, qxy, qz);
+    } else {
+        hipLaunchKernelGGL(k_ghost_gather<false>, dim3(cdiv(n_entries, WG)), dim3(WG), 0, s, n_entries, entries, codes,
+                           x, y, z, m, p->G, p->domain_size, rec, fx, fy, fz, quant, qxy, qz);
+    }
 
     // 3. list of targets in sorted order (every particle a target: built in front of the read-back, above)
     CHK(g.tgt.order.ensure(sizeof(int) * n_tgt));
@@ -714,6 +732,7 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     // 4. pairs
     P3MArgs a{};
     a.rec = rec; a.fx = fx; a.fy = fy; a.fz = fz; a.prefilter_sq = p3m_prefilter_bound(p, grid);
+    a.qxy = qxy; a.qz = qz; a.qbound = qbound;
     a.entries = entries; a.cell_start = start; a.tlist = tlist;
     a.n_entries = n_entries; a.n_tgt = n_tgt; a.tgt_begin = tgt_begin; a.g = grid;
     a.ax = ax; a.ay = ay; a.az = az;
@@ -724,8 +743,8 @@ int run_p3m_cells(const nbpp_params* p, int n_src, const double* x, const double
     g.stats.p3m_pooled = 0;
     if (sym) {
         const dim3 bricks(nbx * nby * nbz);
-        if (soft0) hipLaunchKernelGGL((k_p3m_sym<true>), bricks, dim3(SYM_WG), 0, s, a, nbx, nby, nbz);
-        else hipLaunchKernelGGL((k_p3m_sym<false>), bricks, dim3(SYM_WG), 0, s, a, nbx, nby, nbz);
+        if (soft0) hipLaunchKernelGGL((k_p3m_sym<true>), bricks, dim3(SYM_WG), 0, s, a, brick, nbx, nby, nbz);
+        else hipLaunchKernelGGL((k_p3m_sym<false>), bricks, dim3(SYM_WG), 0, s, a, brick, nbx, nby, nbz);
         HIPCHK(hipGetLastError());
         g.stats.p3m_pooled = 2;
         g.stats.pairs_evaluated = 0;
@@ -895,6 +914,15 @@ int compute_in_order(const nbpp_params* p, size_t n_src, const double* x, const 
             unsigned long long hits = 0;
             for (int i = 0; i < P3M_COUNT_STRIPES; ++i) hits += stripes[i * P3M_COUNT_STRIDE];
             g.stats.pairs_accepted = hits;
+#ifdef NBPP_SYM_STATS
+            unsigned long long d[8] = {};
+            for (int i = 0; i < P3M_COUNT_STRIPES; ++i)
+                for (int w = 1; w < 8; ++w) d[w] += stripes[i * P3M_COUNT_STRIDE + w];
+            if (d[7])
+                std::fprintf(stderr, "sym stats: waves %llu, per wave: trips %.1f rows %.1f drain pair-steps %.1f (live lanes %.1f%%), "
+                             "per target: candidates %.1f survivors %.1f\n", d[7], double(d[1]) / d[7], double(d[2]) / d[7],
+                             double(d[3]) / d[7], 100.0 * d[4] / (64.0 * d[3]), double(d[5]) / (64.0 * d[7]), double(d[6]) / (64.0 * d[7]));
+#endif
         } else {
             unsigned long long tc[2] = {0, 0};
             HIPCHK(hipMemcpy(tc, g.counter.p, sizeof(tc), hipMemcpyDeviceToHost));

@@ -860,15 +860,35 @@ __global__ void k_ghost_scatter(int n, const double* __restrict__ x, const doubl
     });
 }
 
+// The pair-once kernel's filter reads every candidate's position as three 16-bit integers: x and y
+// in one word, z in a half word.  The kernel fetches each lane's own candidates - a gather, which the
+// texture-address path issues at a fixed rate per instruction however few bytes come back - and
+// fp32 coordinates took six 16-byte fetches per trip of eight candidates where these take three.
+// q = round((coordinate - lo) * scale) with [lo, lo + 65535 / scale] covering the ghost layers;
+// two positions a distance r apart differ by at most r * scale + sqrt(3) in these units (each
+// component is off by at most one), which is what the integer bound allows for.
+struct SymQuant {
+    double lo, scale;
+};
+__device__ __forceinline__ unsigned sym_quantise(double c, const SymQuant& q) {
+    const double v = (c - q.lo) * q.scale + 0.5;
+    return static_cast<unsigned>(fmin(fmax(v, 0.0), 65535.0));
+}
+
 __device__ __forceinline__ double image_shift(unsigned code2, double L) {
     return code2 == 1u ? L : (code2 == 2u ? -L : 0.0);
 }
 
+// QUANT = false: the fp32 copies of the positions, one array per axis, for the cutoff pre-filter of
+// k_p3m_cells, k_p3m_pool and k_p3m_rows_pool.  QUANT = true: 16-bit integer positions for k_p3m_sym's,
+// x | y << 16 in `qxy`, z in `qz` (the float arrays are not written).
+template <bool QUANT>
 __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
                                const uint8_t* __restrict__ codes, const double* __restrict__ x, const double* __restrict__ y,
                                const double* __restrict__ z, const double* __restrict__ m,
                                double G, double L, double4* __restrict__ rec,
-                               float* __restrict__ fx, float* __restrict__ fy, float* __restrict__ fz) {
+                               float* __restrict__ fx, float* __restrict__ fy, float* __restrict__ fz,
+                               SymQuant q, uint32_t* __restrict__ qxy, uint16_t* __restrict__ qz) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_entries) return;
     const int i = entries[p];
@@ -877,13 +897,16 @@ __global__ void k_ghost_gather(int n_entries, const int* __restrict__ entries,
                                    canonical(y[i], L) + image_shift((code >> 2) & 3u, L),
                                    canonical(z[i], L) + image_shift((code >> 4) & 3u, L), G * m[i]);
     rec[p] = r;
-    // single-precision copies for the cutoff pre-filter of k_p3m_cells, one array per axis
-    fx[p] = static_cast<float>(r.x);
-    fy[p] = static_cast<float>(r.y);
-    fz[p] = static_cast<float>(r.z);
+    if constexpr (QUANT) {
+        qxy[p] = sym_quantise(r.x, q) | (sym_quantise(r.y, q) << 16);
+        qz[p] = static_cast<uint16_t>(sym_quantise(r.z, q));
+    } else {
+        fx[p] = static_cast<float>(r.x);
+        fy[p] = static_cast<float>(r.y);
+        fz[p] = static_cast<float>(r.z);
+    }
 }
 
-// Targets = real (code 0) entries whose original index lies in [tgt_begin, tgt_begin+n_tgt).
 __global__ void k_target_flags(int n_entries, const int* __restrict__ entries,
                                const uint8_t* __restrict__ codes, int tgt_begin, int n_tgt,
                                int* __restrict__ flag) {
@@ -1010,6 +1033,9 @@ struct P3MArgs {
     const float* fy;         // axis, each n_entries + P3M_TRIP long
     const float* fz;
     float prefilter_sq;      // fp32 r^2 bound that no pair with r^2 <= cutoff_sq can exceed
+    const uint32_t* qxy;     // k_p3m_sym instead of fx, fy, fz: positions as 16-bit integers (SymQuant), x | y << 16
+    const uint16_t* qz;      // and z, each n_entries + 8 long
+    int qbound;              // integer r^2 bound in those units that no pair inside the cutoff can exceed
     const int* entries;      // original index of every sorted record
     const int* cell_start;   // [np^3 + 1]
     const int* tlist;        // sorted positions of the targets
@@ -1848,7 +1874,7 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
 // is then met by exactly one of its two members (the image of a forward offset is a backward one).
 //
 // The reaction a_j has to be added to a particle another lane, wavefront or workgroup may be
-// adding to as well.  A workgroup therefore owns a BRICK of SYM_BX x SYM_BY x SYM_BZ search
+// adding to as well.  A workgroup therefore owns a BRICK of bx x by x bz (SymBrick) search
 // cells: its targets are the brick's real entries, and every source they can meet lies in the
 // region [x0, x0 + BX + R) x [y0 - R, y0 + BY + R) x [z0 - R, z0 + BZ + R), a few dozen columns
 // whose z segments are contiguous runs of the sorted records.  One fp64 sum triple per region
@@ -1859,16 +1885,26 @@ __global__ void __launch_bounds__(64) k_p3m_rows_pool(const P3MArgs a) {
 // ---------------------------------------------------------------------------------
 constexpr int SYM_WG = 512;         // 8 wavefronts per brick; two bricks share a CU's LDS, so one's set-up and
                                     // flush run beside the other's pair loop
-constexpr int SYM_BX = 4, SYM_BY = 4, SYM_BZ = 14;   // ~440 targets at two particles per search cell
+// A brick's extent in search cells: chosen per call (sym_brick) so that a brick holds about 440 targets at
+// the density the search grid was laid out for, whatever the search radius.
+struct SymBrick { int bx, by, bz; };
+constexpr int SYM_MAXPIECE = 36;    // target columns of a brick (bx * by) the tables are sized for
 constexpr int SYM_CAP = 1920;       // region entries whose sums fit in LDS (45 KiB)
-constexpr bool SYM_PREFETCH = false;   // request trip i + 1's coordinates before trip i is tested: 24 more
-                                       // registers, which four record fetches per drain step use better
-                                       // (256^3: 4.67 ms against 4.81 with the prefetch and two fetches)
 constexpr int SYM_DU = 4;           // record fetches in flight per lane while draining
 constexpr int SYM_MAXR = 3;         // search radius in cells the tables are sized for
 constexpr int SYM_RETRY_CALLS = 16; // calls between two tries of the pre-pass once a brick region did not fit
-constexpr int SYM_MAXCOL = (SYM_BX + SYM_MAXR) * (SYM_BY + 2 * SYM_MAXR);
-constexpr int SYM_JBITS = 25;       // ring entries: region column << 25 | sorted position
+constexpr int SYM_MAXCOL = 128;     // region columns ((bx + R) * (by + 2 R)) the tables are sized for
+constexpr int SYM_LIST = 16;        // list entries per lane (one per trip with a survivor)
+constexpr int SYM_JBITS = 25;       // (sorted positions the launch logic lets this kernel see: below 2^25)
+constexpr int SYM_TRIP = 8;         // candidates a lane tests per trip of the filter
+static_assert(SYM_TRIP == 8 && SYM_MAXCOL <= 128 && SYM_CAP <= 2048 && SYM_LIST >= 2, "list entry layout of k_p3m_sym");
+static_assert(SYM_MAXPIECE <= 64, "one wavefront sums the piece lengths");
+
+// 2R x 2R x 7R cells: the same physical brick (1 x 1 x 3.5 cutoff radii) for every search radius R
+__host__ __device__ inline SymBrick sym_brick(int R) { return SymBrick{2 * R, 2 * R, 7 * R}; }
+__host__ __device__ inline bool sym_brick_fits(const SymBrick& b, int R) {
+    return R <= SYM_MAXR && b.bx * b.by <= SYM_MAXPIECE && (b.bx + R) * (b.by + 2 * R) <= SYM_MAXCOL;
+}
 
 // S (f_pp - f_pm) of src/particles.cpp:330-355 for r^2 <= cutoff_sq (without G m and d).
 template <bool SOFT0>
@@ -1894,17 +1930,17 @@ __device__ __forceinline__ double p3m_factor(double r2, const PairConsts& k) {
 
 // Largest number of region entries over all bricks: the launch falls back to k_p3m_cells when
 // one does not fit SYM_CAP (a clustered set).
-__global__ void k_sym_region_max(GhostGrid g, const int* __restrict__ cell_start, int nbx, int nby, int nbz,
+__global__ void k_sym_region_max(GhostGrid g, const int* __restrict__ cell_start, SymBrick bk, int nbx, int nby, int nbz,
                                  unsigned long long* __restrict__ out) {
     // one thread per brick, bz fastest: neighbouring threads read neighbouring words of the same columns
     const int brick = blockIdx.x * blockDim.x + threadIdx.x;
     int total = 0;
     if (brick < nbx * nby * nbz) {
         const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
-        const int x0 = g.R + bx * SYM_BX, y0 = g.R + by * SYM_BY, z0 = g.R + bz * SYM_BZ;
-        const int zlo = z0 - g.R, zhi = min(z0 + SYM_BZ, g.R + g.nside) + g.R;
-        for (int rx = 0; rx < SYM_BX + g.R; ++rx)
-            for (int ry = 0; ry < SYM_BY + 2 * g.R; ++ry) {
+        const int x0 = g.R + bx * bk.bx, y0 = g.R + by * bk.by, z0 = g.R + bz * bk.bz;
+        const int zlo = z0 - g.R, zhi = min(z0 + bk.bz, g.R + g.nside) + g.R;
+        for (int rx = 0; rx < bk.bx + g.R; ++rx)
+            for (int ry = 0; ry < bk.by + 2 * g.R; ++ry) {
                 const int px = x0 + rx, py = y0 - g.R + ry;
                 if (px >= g.np || py >= g.np) continue;
                 const int col = (px * g.np + py) * g.np;
@@ -1916,12 +1952,12 @@ __global__ void k_sym_region_max(GhostGrid g, const int* __restrict__ cell_start
 }
 
 template <bool SOFT0>
-__global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx, int nby, int nbz) {
-    __shared__ double acc[3][SYM_CAP];
-    __shared__ int queue[P3M_QCAP][SYM_WG];
-    __shared__ int col_off[SYM_MAXCOL + 1];    // first LDS entry of every region column
-    __shared__ int col_delta[SYM_MAXCOL];      // LDS entry = sorted position + col_delta[column]
-    __shared__ int piece_off[SYM_BX * SYM_BY + 1], piece_start[SYM_BX * SYM_BY];   // the brick's targets, column by column
+__global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, SymBrick bk, int nbx, int nby, int nbz) {
+    __shared__ double acc[3][SYM_CAP];                     // the reaction sums of every region entry
+    __shared__ int list[SYM_LIST][SYM_WG];                 // per lane: the filter's survivors, one entry per trip
+    __shared__ int col_off[SYM_MAXCOL + 1];                // first LDS slot of every region column
+    __shared__ int col_delta[128];             // LDS slot = sorted position + col_delta[column] (SYM_MAXCOL used; a list entry's 7-bit column field can always be looked up)
+    __shared__ int piece_off[SYM_MAXPIECE + 1], piece_start[SYM_MAXPIECE];   // the brick's targets, column by column
     const GhostGrid g = a.g;
     const PairConsts k = a.k;
     const int b = static_cast<int>(blockIdx.x);      // XCD-aware order of the bricks: see k_p3m_cells
@@ -1930,9 +1966,9 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
     const bool whole = (group + 1) * (8 * P3M_XCD_RUN) <= static_cast<int>(gridDim.x);
     const int brick = whole ? group * (8 * P3M_XCD_RUN) + (in_group % 8) * P3M_XCD_RUN + in_group / 8 : b;
     const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
-    const int x0 = g.R + bx * SYM_BX, y0 = g.R + by * SYM_BY, z0 = g.R + bz * SYM_BZ;
-    const int z1 = min(z0 + SYM_BZ, g.R + g.nside);       // the brick's real cells end here
-    const int CY = SYM_BY + 2 * g.R, ncols = (SYM_BX + g.R) * CY;
+    const int x0 = g.R + bx * bk.bx, y0 = g.R + by * bk.by, z0 = g.R + bz * bk.bz;
+    const int z1 = min(z0 + bk.bz, g.R + g.nside);       // the brick's real cells end here
+    const int CY = bk.by + 2 * g.R, ncols = (bk.bx + g.R) * CY, npieces = bk.bx * bk.by;
     const int tid = threadIdx.x;
 
     // ---- the region's columns and the brick's target pieces
@@ -1948,8 +1984,8 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
         col_delta[tid] = first;      // for now: the column's first sorted position
         col_off[tid + 1] = count;    // for now: its length
     }
-    if (tid < SYM_BX * SYM_BY) {
-        const int rx = tid / SYM_BY, ry = tid - rx * SYM_BY;
+    if (tid < npieces) {
+        const int rx = tid / bk.by, ry = tid - rx * bk.by;
         const int px = x0 + rx, py = y0 + ry;
         int first = 0, count = 0;
         if (px < g.R + g.nside && py < g.R + g.nside) {
@@ -1981,19 +2017,19 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
         if (tid == 0) col_off[0] = 0;
     } else if (tid < 128) {       // second wavefront: the same for the target pieces
         const int l = tid - 64;
-        const int count = l < SYM_BX * SYM_BY ? piece_off[l + 1] : 0;
+        const int count = l < npieces ? piece_off[l + 1] : 0;
         int incl = count;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(incl, d, 64);
             incl += l >= d ? up : 0;
         }
-        if (l < SYM_BX * SYM_BY) piece_off[l + 1] = incl;
+        if (l < npieces) piece_off[l + 1] = incl;
         if (l == 0) piece_off[0] = 0;
     }
     __syncthreads();
     const int n_region = col_off[ncols];
-    const int n_mine = piece_off[SYM_BX * SYM_BY];
+    const int n_mine = piece_off[npieces];
     for (int e = tid; e < n_region; e += SYM_WG) {
         acc[0][e] = 0.0;
         acc[1][e] = 0.0;
@@ -2001,19 +2037,23 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
     }
     __syncthreads();
 
-    const float bound = a.prefilter_sq;
-    const uint32_t f_bytes = static_cast<uint32_t>(a.n_entries + P3M_TRIP) << 2;
-    const __amdgpu_buffer_rsrc_t fx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fx), 0, f_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fy), 0, f_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t fz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fz), 0, f_bytes, 0x00020000);
+    // quantised candidate positions: x | y << 16 per entry, z in a half word per entry (SYM_TRIP entries of
+    // padding behind both, so a trip that starts at a valid entry never leaves the buffers)
+    const uint32_t qxy_bytes = static_cast<uint32_t>(a.n_entries + SYM_TRIP) << 2, qz_bytes = static_cast<uint32_t>(a.n_entries + SYM_TRIP) << 1;
+    const __amdgpu_buffer_rsrc_t qxy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.qxy), 0, qxy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.qz), 0, qz_bytes, 0x00020000);
+    const int nbound = -(a.qbound + 1);       // r_q^2 + nbound < 0  <=>  r_q^2 <= qbound
+    const StartTable<true> starts = make_start_table<true>(a.cell_start, g);
     const uint32_t rec_bytes = static_cast<uint32_t>(a.n_entries) << 5;
     const __amdgpu_buffer_rsrc_t rec_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(a.rec), 0, rec_bytes, 0x00020000);
     const int span = 2 * g.R + 1;
     const int n_rows = g.R * span + g.R + 1;     // the own row, then every row after it in (x, y) order
-    const StartTable<true> starts = make_start_table<true>(a.cell_start, g);
     unsigned long long hits = 0;
     constexpr int DU = SYM_DU;
+#ifdef NBPP_SYM_STATS
+    unsigned long long dbg_trips = 0, dbg_rows = 0, dbg_steps = 0, dbg_live = 0, dbg_cand = 0, dbg_surv = 0;
+#endif
 
 #pragma unroll 1
     for (int chunk = 0; chunk * SYM_WG < n_mine; ++chunk) {
@@ -2021,33 +2061,65 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
         const bool live = t < n_mine;
         if (!__any(live)) continue;          // a wavefront without targets in this chunk
         int piece = 0;
-#pragma unroll
-        for (int c = 1; c < SYM_BX * SYM_BY; ++c) piece += (live && t >= piece_off[c]) ? 1 : 0;
+        for (int c = 1; c < npieces; ++c) piece += (live && t >= piece_off[c]) ? 1 : 0;
         const int p = live ? piece_start[piece] + (t - piece_off[piece]) : 0;
         const double4 me = a.rec[p];
-        const p3m_vf nmx = -a.fx[p], nmy = -a.fy[p], nmz = -a.fz[p];
-        const int rcx = piece / SYM_BY, rcy = piece - rcx * SYM_BY + g.R;   // own column inside the region
+        const int rcx = piece / bk.by, rcy = piece - rcx * bk.by + g.R;   // own column inside the region
+        const int own = live ? p + col_delta[rcx * CY + rcy] : 0;           // own LDS slot
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        const s2 txy = __builtin_bit_cast(s2, a.qxy[p]);                    // own quantised x | y
+        const unsigned tz1 = a.qz[p];
+        const s2 tzz = __builtin_bit_cast(s2, tz1 | (tz1 << 16));           // own quantised z, twice
         const int pcx = x0 + rcx, pcy = y0 + rcy - g.R;
         const int pcz = bin_coord(me.z, g.scale, g.nside) + g.R;
         const RowTrim trim = make_row_trim(me, pcx, pcy, pcz, g, k);
         double ax = 0.0, ay = 0.0, az = 0.0;
-        int rp = 0, wp = 0;
-        int lim = P3M_QCAP - P3M_TRIP;
+        int cnt = 0;                 // entries in this lane's list (at most SYM_LIST)
 
-        auto drain = [&](int quota) {
-            const int cnt = wp - rp;
+        // The filter leaves, per trip of SYM_TRIP candidates with at least one survivor, ONE list entry:
+        //   bits 0-7   which of the trip's candidates survived (candidate u at bit 7 - u),
+        //   bits 8-14  the region column of the row,
+        //   bits 15-25 the LDS slot of the trip's first candidate (sorted position + col_delta[column]).
+        // Evaluating pops the bits: every lane walks its own list at its own pace, a pair per step, until
+        // all lists of the wavefront are empty.  The next entry and the col_delta of its column (slot
+        // - col_delta = the source's sorted position, where its fp64 record lies) are fetched from LDS
+        // one entry ahead of their use, so a lane that moves to its next entry never waits for LDS.
+        // (Letting an evaluation stop early, with the rest waiting in a ring for the next one, was measured:
+        // the lists rarely fill before the rows are used up, so there is one evaluation per wavefront
+        // anyway and its length is that of the lane with the most pairs; no gain.)
+        auto drain_all = [&]() {
+            int rd = 0;                                       // entries that have entered the pipeline
+            unsigned e_next = static_cast<unsigned>(list[0][tid]);
+            unsigned e_after = static_cast<unsigned>(list[1][tid]);
+            int d_next = col_delta[(e_next >> 8) & 127u];
+            unsigned mask = 0u;
+            int base7 = 0, delta = 0;
 #pragma unroll 1
-            for (int q = 0; q < quota && __any(q < cnt); q += DU) {
+            while (__any(mask != 0u || rd < cnt)) {
                 double4 s[DU];
                 bool valid[DU];
                 int slot[DU];
 #pragma unroll
                 for (int u = 0; u < DU; ++u) {
-                    valid[u] = q + u < cnt;
-                    const unsigned e = valid[u] ? static_cast<unsigned>(queue[ring_slot(rp + q + u)][tid]) : 0u;
-                    const unsigned jj = e & ((1u << SYM_JBITS) - 1u);
-                    slot[u] = static_cast<int>(jj) + col_delta[e >> SYM_JBITS];
+                    if (mask == 0u && rd < cnt) {             // on to the next entry (never an empty one)
+                        mask = e_next & 255u;
+                        base7 = static_cast<int>(e_next >> 15) + 7;
+                        delta = d_next;
+                        e_next = e_after;
+                        d_next = col_delta[(e_after >> 8) & 127u];
+                        ++rd;
+                        e_after = static_cast<unsigned>(list[min(rd + 1, SYM_LIST - 1)][tid]);
+                    }
+                    valid[u] = mask != 0u;
+                    const int bit = __builtin_ctz(mask | 0x100u);
+                    mask &= mask - 1u;
+                    slot[u] = base7 - bit;
+                    const unsigned jj = static_cast<unsigned>(slot[u] - delta);
                     s[u] = load_record_checked(rec_rsrc, valid[u] ? jj << 5 : 0xffffffe0u);
+#ifdef NBPP_SYM_STATS
+                    dbg_steps += 1;
+                    dbg_live += __popcll(__builtin_amdgcn_ballot_w64(valid[u]));
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < DU; ++u) {
@@ -2057,25 +2129,24 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
                     hits += __popcll(__builtin_amdgcn_ballot_w64(accept));   // the wavefront's count, kept on the scalar side
                     if (accept) {
                         const double f = p3m_factor<SOFT0>(r2, k);
-                        const double fx = f * dx, fy = f * dy, fz = f * dz;
-                        ax = __builtin_fma(s[u].w, fx, ax);    // a_i += G m_j f d
-                        ay = __builtin_fma(s[u].w, fy, ay);
-                        az = __builtin_fma(s[u].w, fz, az);
-                        const double ngm = -me.w;              // a_j -= G m_i f d
-                        __hip_atomic_fetch_add(&acc[0][slot[u]], ngm * fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&acc[1][slot[u]], ngm * fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&acc[2][slot[u]], ngm * fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const double fi = s[u].w * f;          // a_i += G m_j f d
+                        ax = __builtin_fma(fi, dx, ax);
+                        ay = __builtin_fma(fi, dy, ay);
+                        az = __builtin_fma(fi, dz, az);
+                        const double fj = -me.w * f;           // a_j -= G m_i f d
+                        __hip_atomic_fetch_add(&acc[0][slot[u]], fj * dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&acc[1][slot[u]], fj * dy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&acc[2][slot[u]], fj * dz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
-            rp += min(quota, cnt);
-            lim = rp + (P3M_QCAP - P3M_TRIP);
+            cnt = 0;
         };
 
         // row r: 0 the own row (entries behind p only), 1..R the rows (0, 1..R), then (1..R, -R..R);
         // called with r = 0, 1, 2, ...: (ox, oy) step along
         int ox = 0, oy = -1;
-        auto row_bounds = [&](int r, int& first, int& last, int& tg) {
+        auto row_bounds = [&](int r, int& first, int& last, int& tg, int& dl) {
             ++oy;
             if (oy > g.R) { oy = -g.R; ++ox; }
             int zlo, zhi;                       // the part of the row this particle can reach
@@ -2084,70 +2155,67 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
             first = load_start(starts, base + zlo, has);
             last = load_start(starts, base + zhi + 1, has);
             if (r == 0) first = has ? p + 1 : 0;
-            tg = ((rcx + ox) * CY + (rcy + oy)) << SYM_JBITS;
+            const int col = min((rcx + ox) * CY + (rcy + oy), SYM_MAXCOL - 1);   // (lanes without a row: any valid column)
+            tg = col << 8;
+            dl = col_delta[col];
         };
         int round = 0;
-        int j = 0, je = 0, tag = 0;
-        int nj, nje, ntag;
-        row_bounds(0, nj, nje, ntag);
-        // moves (j, je, tag) to the next trip of P3M_TRIP candidates; false once the rows are used up
+        int j = 0, jb = 0, je = 0, tag = 0, dlt = 0;      // the run is [jb, je); trips start at even positions
+        int nj, nje, ntag, ndlt;
+        row_bounds(0, nj, nje, ntag, ndlt);
+        // moves (j, jb, je, tag, dlt) to the next trip of SYM_TRIP candidates; false once the rows are used up
         auto next_trip = [&]() -> bool {
-            j += P3M_TRIP;
+            j += SYM_TRIP;
             if (!__any(j < je)) {
                 if (round == n_rows) return false;
-                j = nj; je = nje; tag = ntag;
+                jb = nj; je = nje; tag = ntag; dlt = ndlt;
+                j = jb & ~1;                    // an even position: the half words of z then start on a word
                 ++round;
-                row_bounds(round, nj, nje, ntag);
+#ifdef NBPP_SYM_STATS
+                dbg_rows += 1;
+#endif
+                row_bounds(round, nj, nje, ntag, ndlt);
             }
             return true;
         };
-        auto fetch = [&](p3m_vf& vx, p3m_vf& vy, p3m_vf& vz) {
-            const uint32_t off = j < je ? static_cast<uint32_t>(j) << 2 : 0xfffffff0u;
-            vx = load_fvec_checked(fx_rsrc, off);
-            vy = load_fvec_checked(fy_rsrc, off);
-            vz = load_fvec_checked(fz_rsrc, off);
-        };
-        // the coordinates of trip i + 1 are requested before trip i is tested and queued, so that
-        // their latency runs beside that work (only four wavefronts share a SIMD here); two
-        // register sets take turns, so nothing is copied
-        auto test_and_queue = [&](const p3m_vf& cx, const p3m_vf& cy, const p3m_vf& cz, int cj, int cje, int ctag) {
-            const p3m_vf dx = cx + nmx, dy = cy + nmy, dz = cz + nmz;
-            const p3m_vf r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
-            const int left = cje - cj;          // candidates of this trip that belong to the run
-            const int first = ctag | cj;
+#pragma unroll 1
+        while (next_trip()) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            if (j < je) {                       // (an exhausted lane fetches and tests nothing)
+                const u4 xy0 = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qxy_rsrc, static_cast<uint32_t>(j) << 2, 0, 0));
+                const u4 xy1 = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qxy_rsrc, (static_cast<uint32_t>(j) << 2) + 16u, 0, 0));
+                const u4 zz = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qz_rsrc, static_cast<uint32_t>(j) << 1, 0, 0));
+                // r_q^2 + nbound per candidate in exact integer arithmetic: packed 16-bit differences, x^2 + y^2
+                // by v_dot2, z^2 by a 24-bit multiply-add; its sign bit is set <=> the candidate may lie inside
+                // the cutoff.  The eight sign bits are shifted into one word, first candidate first (v_alignbit).
+                unsigned bits = 0u;
 #pragma unroll
-            for (int u = 0; u < P3M_TRIP; ++u) {
-                queue[ring_slot(wp)][tid] = first + u;
-                wp += ((u < left) & !(r2[u] > bound)) ? 1 : 0;
+                for (int u = 0; u < SYM_TRIP; ++u) {
+                    // (vector elements go through scalars: a bit cast of the element itself reads element 0)
+                    const unsigned cxy = u < 4 ? xy0[u & 3] : xy1[u & 3];
+                    const unsigned czz = zz[u >> 1];
+                    const s2 dxy = __builtin_bit_cast(s2, cxy) - txy;
+                    const s2 dzz = __builtin_bit_cast(s2, czz) - tzz;
+                    const int dz = (u & 1) ? dzz.y : dzz.x;
+                    const int rq = __builtin_amdgcn_sdot2(dxy, dxy, dz * dz + nbound, false);
+                    bits = __builtin_amdgcn_alignbit(bits, static_cast<unsigned>(rq), 31);
+                }
+                // only positions jb <= j + u < je belong to the run
+                const int lead = max(jb - j, 0), left = min(je - j, SYM_TRIP);
+                const unsigned mask = bits & (0xffu >> lead) & (0xff00u >> left);
+#ifdef NBPP_SYM_STATS
+                dbg_trips += 1;
+                for (int u = 0; u < SYM_TRIP; ++u) dbg_cand += __popcll(__builtin_amdgcn_ballot_w64(u >= lead && u < left));
+                for (int u = 0; u < SYM_TRIP; ++u) dbg_surv += __popcll(__builtin_amdgcn_ballot_w64((mask >> (7 - u)) & 1u));
+#endif
+                // (cnt < SYM_LIST here: a full list is drained at once, below)
+                list[cnt][tid] = static_cast<int>((static_cast<unsigned>(j + dlt) << 15) | static_cast<unsigned>(tag) | mask);
+                cnt += mask != 0u ? 1 : 0;
             }
-            if (__any(wp > lim)) drain(P3M_DRAIN);
-        };
-        p3m_vf ax0 = 0.0f, ay0 = 0.0f, az0 = 0.0f, ax1 = 0.0f, ay1 = 0.0f, az1 = 0.0f;
-        bool more = next_trip();
-        if constexpr (!SYM_PREFETCH) {
-#pragma unroll 1
-            while (more) {
-                fetch(ax0, ay0, az0);
-                test_and_queue(ax0, ay0, az0, j, je, tag);
-                more = next_trip();
-            }
+            if (__any(cnt >= SYM_LIST)) drain_all();      // some lane's list is full (not on an even set)
         }
-        if (more) fetch(ax0, ay0, az0);
-#pragma unroll 1
-        while (more) {
-            int cj = j, cje = je, ctag = tag;
-            more = next_trip();
-            if (more) fetch(ax1, ay1, az1);
-            test_and_queue(ax0, ay0, az0, cj, cje, ctag);
-            if (!more) break;
-            cj = j; cje = je; ctag = tag;
-            more = next_trip();
-            if (more) fetch(ax0, ay0, az0);
-            test_and_queue(ax1, ay1, az1, cj, cje, ctag);
-        }
-        while (__any(wp > rp)) drain(P3M_QCAP);
+        drain_all();
         if (live) {   // the target's own sums join what others add to it
-            const int own = p + col_delta[rcx * CY + rcy];
             __hip_atomic_fetch_add(&acc[0][own], ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&acc[1][own], ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&acc[2][own], az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2184,6 +2252,13 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, int nbx,
     if (a.accepted) {
         const unsigned long long h = 2ull * hits;    // both members of every pair
         if ((tid & 63) == 0 && h) atomicAdd(accepted_stripe(a.accepted), h);
+#ifdef NBPP_SYM_STATS
+        if ((tid & 63) == 0) {
+            unsigned long long* d = accepted_stripe(a.accepted);
+            atomicAdd(d + 1, dbg_trips); atomicAdd(d + 2, dbg_rows); atomicAdd(d + 3, dbg_steps);
+            atomicAdd(d + 4, dbg_live); atomicAdd(d + 5, dbg_cand); atomicAdd(d + 6, dbg_surv); atomicAdd(d + 7, 1ull);
+        }
+#endif
     }
 }
 
