@@ -1890,7 +1890,7 @@ constexpr int SYM_WG = 512;         // 8 wavefronts per brick; two bricks share 
 struct SymBrick { int bx, by, bz; };
 constexpr int SYM_MAXPIECE = 36;    // target columns of a brick (bx * by) the tables are sized for
 constexpr int SYM_CAP = 1920;       // region entries whose sums fit in LDS (45 KiB)
-constexpr int SYM_DU = 4;           // record fetches in flight per lane while draining
+constexpr int SYM_DU = 4;           // record fetches in flight per lane while draining (2 / 3 / 4 / 6: 4.79 / 4.47 / 4.39 / 4.37 ms at 256^3)
 constexpr int SYM_MAXR = 3;         // search radius in cells the tables are sized for
 constexpr int SYM_RETRY_CALLS = 16; // calls between two tries of the pre-pass once a brick region did not fit
 constexpr int SYM_MAXCOL = 128;     // region columns ((bx + R) * (by + 2 R)) the tables are sized for

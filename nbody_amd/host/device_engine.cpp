@@ -74,9 +74,16 @@ void DeviceEngine::construct(std::size_t n_total, const double* const (&state)[1
     // (not with several ranks: the collectives of one communicator must be issued in one order,
     // which two streams do not give)
     if (config_.USE_PM && config_.USE_PP && n_ && ranks_ <= 1) {
-        // (a higher or a lower priority for this stream was measured: 1.61 and 1.60 ms per cycle at 128^3
-        // against 1.58 with equal priorities)
-        hip_check(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&pp_stream_), hipStreamNonBlocking), "hipStreamCreate");
+        // Its own HARDWARE queue: a process has four of them for all its streams of normal priority
+        // (GPU_MAX_HW_QUEUES), handed out by use count, and a fifth stream anywhere in the process -
+        // a library's private one, the runtime's own copy queue - can leave this one sharing the main
+        // stream's queue, where the two run strictly one after the other (1.79 instead of 1.53 ms per
+        // cycle at 128^3, seen once the initial conditions moved to the device).  Streams of another
+        // priority have a pool of queues of their own.  Highest priority 1.53 ms per cycle, lowest 1.59.
+        int least = 0, greatest = 0;
+        hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+        hip_check(hipStreamCreateWithPriority(reinterpret_cast<hipStream_t*>(&pp_stream_), hipStreamNonBlocking, greatest),
+                  "hipStreamCreateWithPriority");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pos_), hipEventDisableTiming), "hipEventCreate");
         hip_check(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_pp_), hipEventDisableTiming), "hipEventCreate");
         for (double*& a : pp_acc_) hip_check(hipMalloc(reinterpret_cast<void**>(&a), sizeof(double) * n_), "hipMalloc");

@@ -1210,12 +1210,14 @@ def test_p3m_kernels_agree_on_random_configurations(lib, oracle, seed):
 # P3M cell kernel: every unordered pair once (reactions gathered per brick in LDS)
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,n_side,mesh", [("lattice", 48, 48), ("lattice_r2", 64, 64), ("uneven_grid", 37, 41),
-                                              ("lattice_soft0", 32, 32), ("unequal_masses", 40, 40)])
+                                              ("lattice_soft0", 32, 32), ("unequal_masses", 40, 40),
+                                              ("radius_3", 64, 64)])
 def test_p3m_pair_once_equals_ordered_pairs(lib, oracle, name, n_side, mesh):
     """k_p3m_sym against k_p3m_cells on the same inputs: twice the unordered pairs it evaluates
     must be the ordered-pair count (an exact integer, equal to the oracle's), and the sums must
     agree to rounding.  Grids that are not a multiple of the brick size, both search radii,
-    zero softening and unequal masses (the reaction carries the target's mass)."""
+    zero softening and unequal masses (the reaction carries the target's mass); a search radius of
+    three cells on a set that gets two by itself (the brick's extent in cells follows the radius)."""
     n = n_side ** 3
     pos = datasets.jittered_lattice(n_side, jitter=0.9)
     m = datasets.masses(n, equal=(name != "unequal_masses"))
@@ -1227,6 +1229,7 @@ def test_p3m_pair_once_equals_ordered_pairs(lib, oracle, name, n_side, mesh):
     try:
         lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 1)
         lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, -1)
+        lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, 3 if name == "radius_3" else 0)
         for once in (-1, 1):
             lib.set_option(ffi.OPT_P3M_PAIR_ONCE, once)
             out[once] = gpu_acc(lib, p, pos, m, acc0=[np.full(n, 0.5), np.zeros(n), np.full(n, -2.0)])
@@ -1234,6 +1237,7 @@ def test_p3m_pair_once_equals_ordered_pairs(lib, oracle, name, n_side, mesh):
             assert st["kernel_variant"] == ffi.KERNEL_P3M_CELLS and st["p3m_pooled"] == (2 if once > 0 else 0)
             out[once, "accepted"] = st["pairs_accepted"]
     finally:
+        lib.set_option(ffi.OPT_P3M_SEARCH_RADIUS, 0)
         lib.set_option(ffi.OPT_P3M_LANES_PER_TARGET, 0)
         lib.set_option(ffi.OPT_P3M_POOLED_DRAIN, 0)
         lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
@@ -1260,6 +1264,21 @@ def test_p3m_pair_once_falls_back_on_a_clustered_set(lib):
         assert lib.stats()["p3m_pooled"] != 2
     finally:
         lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
+
+
+def test_p3m_needs_a_positive_mesh_softening(lib):
+    """(r^2 + pm_soft_sq)^(-3/2) is evaluated at r = 0 as well (a target's own record passes the pooled
+    kernels' filter): pm_soft_sq = 0 would put NaN into every sum, so it is refused as an argument
+    error before anything is added.  The reference's (CELL_SIZE / 2)^2 is always positive."""
+    n_side = 16
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side)
+    m = datasets.masses(n, equal=True)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True).pp_params()
+    p.pm_soft_sq = 0.0
+    with pytest.raises(ffi.NbppError) as err:
+        gpu_acc(lib, p, pos, m)
+    assert "pm_soft_sq" in str(err.value)
 
 
 @pytest.mark.parametrize("use_pm", [True, False])
