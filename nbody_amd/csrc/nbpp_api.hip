@@ -443,7 +443,11 @@ int run_allpairs(const nbpp_params* p, int variant, int n_src, const double* x, 
 // several lanes per target, do better with the 49 shorter runs (32^3 at a = 1: 0.21 against
 // 0.25 ms).
 bool p3m_search_grid(const nbpp_params* p, int n_src, int* radius, int* nside) {
+#ifdef NBPP_EXPERIMENT_SKIN_PERCENT   // cells laid out for a cutoff radius this much larger (what a list kept for several steps would need)
+    const double rc = std::sqrt(p->cutoff_sq) * (1.0 + 1e-9) * (1.0 + NBPP_EXPERIMENT_SKIN_PERCENT / 100.0);
+#else
     const double rc = std::sqrt(p->cutoff_sq) * (1.0 + 1e-9);
+#endif
     int R = g.opt_p3m_radius > 0 ? static_cast<int>(g.opt_p3m_radius) : (n_src >= (1 << 17) ? 2 : 3);
     R = std::min(R, 8);
     const double cells = std::floor(R * p->domain_size / rc);

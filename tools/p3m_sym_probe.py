@@ -3,7 +3,7 @@
 build named in NBPP_LIBS (file names under nbody_amd/lib, default libnbpp.so), one child process per
 build: pair kernel and binning time (best of 6 and mean), accepted pairs, and a checksum of the sums.
 
-usage: [NBPP_LIBS="a.so b.so"] tools/p3m_sym_probe.py [--n-side 256] [--pair-once 1|0|-1] [--radius R]
+usage: [NBPP_LIBS="a.so b.so"] tools/p3m_sym_probe.py [--n-side 256] [--pair-once 1|0|-1] [--radius R] [--shuffle]
 """
 import json
 import os
@@ -29,7 +29,11 @@ def child():
     config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
     p = config.pp_params()
     n = n_side ** 3
-    d = [torch.as_tensor(a, device="cuda:0") for a in datasets.jittered_lattice(n_side)] + [
+    pos = datasets.jittered_lattice(n_side)
+    if os.environ.get("PROBE_SHUFFLE"):      # the same particles in random memory order
+        order = np.random.default_rng(7).permutation(n)
+        pos = [np.ascontiguousarray(a[order]) for a in pos]
+    d = [torch.as_tensor(a, device="cuda:0") for a in pos] + [
         torch.full((n,), config.DM_PARTICLE_MASS, dtype=torch.float64, device="cuda:0")]
     acc = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
     ks, ps = [], []
@@ -57,6 +61,8 @@ if __name__ == "__main__":
         env["PROBE_N_SIDE"] = sys.argv[sys.argv.index("--n-side") + 1]
     if "--radius" in sys.argv:
         env["PROBE_RADIUS"] = sys.argv[sys.argv.index("--radius") + 1]
+    if "--shuffle" in sys.argv:
+        env["PROBE_SHUFFLE"] = "1"
     if "--pair-once" in sys.argv:
         env["PROBE_PAIR_ONCE"] = sys.argv[sys.argv.index("--pair-once") + 1]
     for so in os.environ.get("NBPP_LIBS", "libnbpp.so").split():
