@@ -1896,8 +1896,11 @@ constexpr int SYM_RETRY_CALLS = 16; // calls between two tries of the pre-pass o
 constexpr int SYM_MAXCOL = 128;     // region columns ((bx + R) * (by + 2 R)) the tables are sized for
 constexpr int SYM_LIST = 16;        // list entries per lane (one per trip with a survivor)
 constexpr int SYM_JBITS = 25;       // (sorted positions the launch logic lets this kernel see: below 2^25)
-constexpr int SYM_TRIP = 8;         // candidates a lane tests per trip of the filter
-static_assert(SYM_TRIP == 8 && SYM_MAXCOL <= 128 && SYM_CAP <= 2048 && SYM_LIST >= 2, "list entry layout of k_p3m_sym");
+constexpr int SYM_HALF = 8;         // candidates behind one list entry (its mask)
+constexpr int SYM_HALVES = 2;       // list entries a trip of the filter can leave: 16 candidates per trip cover most
+                                    // windows in one trip (1.2 trips per row and wavefront at 256^3 against 1.9 with 8)
+constexpr int SYM_TRIP = SYM_HALF * SYM_HALVES;   // candidates a lane tests per trip of the filter
+static_assert(SYM_HALF == 8 && SYM_TRIP <= 16 && SYM_LIST > SYM_HALVES && SYM_MAXCOL <= 128 && SYM_CAP <= 2048 && SYM_LIST >= 2, "list entry layout of k_p3m_sym");
 static_assert(SYM_MAXPIECE <= 64, "one wavefront sums the piece lengths");
 
 // 2R x 2R x 7R cells: the same physical brick (1 x 1 x 3.5 cutoff radii) for every search radius R
@@ -2181,19 +2184,26 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, SymBrick
 #pragma unroll 1
         while (next_trip()) {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#ifdef NBPP_SYM_STATS
+            dbg_trips += 1;
+#endif
             if (j < je) {                       // (an exhausted lane fetches and tests nothing)
-                const u4 xy0 = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qxy_rsrc, static_cast<uint32_t>(j) << 2, 0, 0));
-                const u4 xy1 = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qxy_rsrc, (static_cast<uint32_t>(j) << 2) + 16u, 0, 0));
-                const u4 zz = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qz_rsrc, static_cast<uint32_t>(j) << 1, 0, 0));
+                u4 xy[2 * SYM_HALVES], zz[SYM_HALVES];
+#pragma unroll
+                for (int h = 0; h < SYM_HALVES; ++h) {
+                    xy[2 * h] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qxy_rsrc, (static_cast<uint32_t>(j) << 2) + 32u * h, 0, 0));
+                    xy[2 * h + 1] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qxy_rsrc, (static_cast<uint32_t>(j) << 2) + 32u * h + 16u, 0, 0));
+                    zz[h] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(qz_rsrc, (static_cast<uint32_t>(j) << 1) + 16u * h, 0, 0));
+                }
                 // r_q^2 + nbound per candidate in exact integer arithmetic: packed 16-bit differences, x^2 + y^2
                 // by v_dot2, z^2 by a 24-bit multiply-add; its sign bit is set <=> the candidate may lie inside
-                // the cutoff.  The eight sign bits are shifted into one word, first candidate first (v_alignbit).
+                // the cutoff.  The sign bits are shifted into one word, first candidate first (v_alignbit).
                 unsigned bits = 0u;
 #pragma unroll
                 for (int u = 0; u < SYM_TRIP; ++u) {
                     // (vector elements go through scalars: a bit cast of the element itself reads element 0)
-                    const unsigned cxy = u < 4 ? xy0[u & 3] : xy1[u & 3];
-                    const unsigned czz = zz[u >> 1];
+                    const unsigned cxy = xy[u >> 2][u & 3];
+                    const unsigned czz = zz[u >> 3][(u >> 1) & 3];
                     const s2 dxy = __builtin_bit_cast(s2, cxy) - txy;
                     const s2 dzz = __builtin_bit_cast(s2, czz) - tzz;
                     const int dz = (u & 1) ? dzz.y : dzz.x;
@@ -2201,18 +2211,23 @@ __global__ void __launch_bounds__(SYM_WG, 4) k_p3m_sym(const P3MArgs a, SymBrick
                     bits = __builtin_amdgcn_alignbit(bits, static_cast<unsigned>(rq), 31);
                 }
                 // only positions jb <= j + u < je belong to the run
+                constexpr unsigned FULL = (1u << SYM_TRIP) - 1u;
                 const int lead = max(jb - j, 0), left = min(je - j, SYM_TRIP);
-                const unsigned mask = bits & (0xffu >> lead) & (0xff00u >> left);
+                const unsigned mask = bits & (FULL >> lead) & ((FULL << SYM_TRIP) >> left);
 #ifdef NBPP_SYM_STATS
-                dbg_trips += 1;
                 for (int u = 0; u < SYM_TRIP; ++u) dbg_cand += __popcll(__builtin_amdgcn_ballot_w64(u >= lead && u < left));
-                for (int u = 0; u < SYM_TRIP; ++u) dbg_surv += __popcll(__builtin_amdgcn_ballot_w64((mask >> (7 - u)) & 1u));
+                for (int u = 0; u < SYM_TRIP; ++u) dbg_surv += __popcll(__builtin_amdgcn_ballot_w64((mask >> (SYM_TRIP - 1 - u)) & 1u));
 #endif
-                // (cnt < SYM_LIST here: a full list is drained at once, below)
-                list[cnt][tid] = static_cast<int>((static_cast<unsigned>(j + dlt) << 15) | static_cast<unsigned>(tag) | mask);
-                cnt += mask != 0u ? 1 : 0;
+                // one entry per group of eight candidates with a survivor (cnt <= SYM_LIST - SYM_HALVES here:
+                // a list without room for a whole trip is drained at once, below)
+#pragma unroll
+                for (int h = 0; h < SYM_HALVES; ++h) {
+                    const unsigned m8 = (mask >> (SYM_HALF * (SYM_HALVES - 1 - h))) & 255u;
+                    list[cnt][tid] = static_cast<int>((static_cast<unsigned>(j + SYM_HALF * h + dlt) << 15) | static_cast<unsigned>(tag) | m8);
+                    cnt += m8 != 0u ? 1 : 0;
+                }
             }
-            if (__any(cnt >= SYM_LIST)) drain_all();      // some lane's list is full (not on an even set)
+            if (__any(cnt > SYM_LIST - SYM_HALVES)) drain_all();      // some lane's list has no room for another trip
         }
         drain_all();
         if (live) {   // the target's own sums join what others add to it
