@@ -1898,7 +1898,7 @@ constexpr int SYM_LIST = 16;        // list entries per lane (one per trip with 
 constexpr int SYM_JBITS = 25;       // (sorted positions the launch logic lets this kernel see: below 2^25)
 constexpr int SYM_HALF = 8;         // candidates behind one list entry (its mask)
 constexpr int SYM_HALVES = 2;       // list entries a trip of the filter can leave: 16 candidates per trip cover most
-                                    // windows in one trip (1.2 trips per row and wavefront at 256^3 against 1.9 with 8)
+                                    // windows in one trip (1.2 trips per row and wavefront at 256^3 against 2.0 with 8)
 constexpr int SYM_TRIP = SYM_HALF * SYM_HALVES;   // candidates a lane tests per trip of the filter
 static_assert(SYM_HALF == 8 && SYM_TRIP <= 16 && SYM_LIST > SYM_HALVES && SYM_MAXCOL <= 128 && SYM_CAP <= 2048 && SYM_LIST >= 2, "list entry layout of k_p3m_sym");
 static_assert(SYM_MAXPIECE <= 64, "one wavefront sums the piece lengths");
