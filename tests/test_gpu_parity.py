@@ -1252,6 +1252,31 @@ def test_p3m_pair_once_equals_ordered_pairs(lib, oracle, name, n_side, mesh):
     assert normalised_error([c[:n_tgt] for c in a], want, floor) < TOL
 
 
+@pytest.mark.parametrize("use_pm,n_side,pair_once", [(True, 96, 0), (True, 64, -1), (False, 40, 0)])
+def test_forces_do_not_depend_on_the_order_of_the_particles_in_memory(lib, use_pm, n_side, pair_once):
+    """f(P x) = P f(x): the same particles handed over in a random order get the same forces, particle by
+    particle, to the rounding of the sums, and exactly the same number of accepted pairs.  The binning
+    gathers records and scatters sums by original index, so this walks a path the lattice-ordered
+    sets never take: neighbours in space that are far apart in memory.  P3M through the pair-once
+    kernel (the library's choice for 96^3) and through the pooled kernel, direct summation through
+    the pair-once all-pairs kernel."""
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side, jitter=0.9)
+    m = datasets.masses(n, equal=False)
+    p = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=use_pm).pp_params()
+    order = np.random.default_rng(11).permutation(n)
+    lib.set_option(ffi.OPT_P3M_PAIR_ONCE, pair_once)
+    try:
+        straight = gpu_acc(lib, p, pos, m)
+        accepted = lib.stats()["pairs_accepted"]
+        shuffled = gpu_acc(lib, p, [np.ascontiguousarray(c[order]) for c in pos], np.ascontiguousarray(m[order]))
+        assert lib.stats()["pairs_accepted"] == accepted
+    finally:
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
+    floor = pair_force_scale(p, m, n) * 1e-3
+    assert normalised_error(shuffled, [c[order] for c in straight], floor) < 1e-10
+
+
 def test_p3m_pair_once_falls_back_on_a_clustered_set(lib):
     """A brick whose neighbourhood does not fit in LDS: the ordinary kernels take the call."""
     n = 64 ** 3
