@@ -1277,6 +1277,34 @@ def test_forces_do_not_depend_on_the_order_of_the_particles_in_memory(lib, use_p
     assert normalised_error(shuffled, [c[order] for c in straight], floor) < 1e-10
 
 
+@pytest.mark.parametrize("pair_once", [0, -1])
+def test_p3m_forces_are_invariant_under_a_shift_of_the_box(lib, pair_once):
+    """The box is periodic: moving every particle by the same vector (and folding back into [0, L))
+    changes which particles sit near the faces, hence every ghost image, every brick and every row
+    window, but no force.  128^3 particles, a shift of a third of the box and an odd fraction of a
+    cell; the folded positions are rounded anew, which moves a pair's separation by ~1e-16 L, so the
+    sums agree to 1e-10 of the pair-force scale and a handful of pairs may cross the cutoff."""
+    n_side = 128
+    n = n_side ** 3
+    pos = datasets.jittered_lattice(n_side, jitter=0.9)
+    m = datasets.masses(n, equal=True)
+    config = Config(MESH_SIZE=n_side, N_PER_SIDE=n_side, USE_PM=True)
+    p = config.pp_params()
+    L = config.DOMAIN_SIZE
+    shift = np.array([1.0 / 3.0, 0.5 + 0.37 / n_side, 0.9991]) * L
+    moved = [np.ascontiguousarray(np.mod(c + s, L)) for c, s in zip(pos, shift)]
+    lib.set_option(ffi.OPT_P3M_PAIR_ONCE, pair_once)
+    try:
+        here = gpu_acc(lib, p, pos, m)
+        accepted = lib.stats()["pairs_accepted"]
+        there = gpu_acc(lib, p, moved, m)
+        assert abs(lib.stats()["pairs_accepted"] - accepted) <= 8
+    finally:
+        lib.set_option(ffi.OPT_P3M_PAIR_ONCE, 0)
+    floor = pair_force_scale(p, m, n) * 1e-3
+    assert normalised_error(there, here, floor) < 1e-9
+
+
 def test_p3m_pair_once_falls_back_on_a_clustered_set(lib):
     """A brick whose neighbourhood does not fit in LDS: the ordinary kernels take the call."""
     n = 64 ** 3
